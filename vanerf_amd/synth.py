@@ -1,0 +1,158 @@
+"""Seeded synthetic frames for tests, smoke() and bench.py (no dataset, no MANO pickle).
+
+Shapes follow what the reference renderer consumes: two closed
+genus-0 "hands" of 779 vertices / 1554 faces each (the vertex/face counts of a sealed MANO
+hand, reference src/dataset.py:35-52, so NV = 1558, NF = 3108 and the twin-vertex roll of
+src/networks.py:30-32 is valid), 42 key points, a 256x256 source image and the three feature
+maps the image encoders produce (src/model.py:971-972).
+"""
+import math
+
+import numpy as np
+import torch
+
+NV_HAND = 779
+NF_HAND = 1554
+
+
+def uv_sphere(rings=21, segs=37):
+    """Unit sphere, outward CCW winding: rings*segs + 2 vertices, 2*segs*rings faces."""
+    verts = [(0.0, 0.0, 1.0)]
+    for r in range(1, rings + 1):
+        th = math.pi * r / (rings + 1)
+        for s in range(segs):
+            ph = 2.0 * math.pi * s / segs
+            verts.append((math.sin(th) * math.cos(ph), math.sin(th) * math.sin(ph), math.cos(th)))
+    verts.append((0.0, 0.0, -1.0))
+    faces = []
+    ring0 = lambda r: 1 + r * segs
+    for s in range(segs):
+        faces.append((0, ring0(0) + s, ring0(0) + (s + 1) % segs))
+    for r in range(rings - 1):
+        for s in range(segs):
+            a, b = ring0(r) + s, ring0(r) + (s + 1) % segs
+            c, d = ring0(r + 1) + s, ring0(r + 1) + (s + 1) % segs
+            faces.append((a, c, d))
+            faces.append((a, d, b))
+    last = len(verts) - 1
+    for s in range(segs):
+        faces.append((last, ring0(rings - 1) + (s + 1) % segs, ring0(rings - 1) + s))
+    return np.asarray(verts, dtype=np.float64), np.asarray(faces, dtype=np.int64)
+
+
+def two_hand_mesh(seed=0, radius=0.05, offset=0.04, depth=1.0, bumpy=True):
+    """(1558,3) float32 vertices, (3108,3) int64 faces; hand 1 is a translated copy of hand 0's topology."""
+    rng = np.random.RandomState(seed)
+    sv, sf = uv_sphere()
+    assert sv.shape[0] == NV_HAND and sf.shape[0] == NF_HAND
+    hands = []
+    for h, cx in enumerate((-offset, offset)):
+        v = sv.copy()
+        if bumpy:  # low-frequency radial displacement keeps the surface closed and star-shaped
+            amp = rng.uniform(0.05, 0.15, size=3)
+            frq = rng.randint(1, 4, size=3)
+            ph = rng.uniform(0, 2 * math.pi, size=3)
+            r = 1.0 + amp[0] * np.sin(frq[0] * np.arctan2(v[:, 1], v[:, 0]) + ph[0]) * (1 - v[:, 2] ** 2) \
+                + amp[1] * np.sin(frq[1] * math.pi * v[:, 2] + ph[1]) * (1 - v[:, 2] ** 2)
+            v = v * r[:, None]
+            v = v * np.array([1.0, 1.3, 0.7])
+        v = v * radius + np.array([cx, 0.003 * (2 * h - 1), depth])
+        hands.append(v)
+    verts = np.concatenate(hands, 0).astype(np.float32)
+    faces = np.concatenate([sf, sf + NV_HAND], 0)
+    return verts, faces
+
+
+def look_at_extrinsic(eye, target, up=(0.0, -1.0, 0.0)):
+    """World->camera 4x4 (x right, y down, z forward)."""
+    eye, target, up = (np.asarray(a, dtype=np.float64) for a in (eye, target, up))
+    z = target - eye
+    z /= np.linalg.norm(z)
+    x = np.cross(-up, z)
+    x /= np.linalg.norm(x)
+    y = np.cross(z, x)
+    R = np.stack([x, y, z], 0)
+    E = np.eye(4)
+    E[:3, :3] = R
+    E[:3, 3] = -R @ eye
+    return E.astype(np.float32)
+
+
+def make_frame(seed=0, tar_h=64, tar_w=64, src_hw=256, orbit_deg=8.0, device="cpu", half_mask=False,
+               focal_src=1500.0):
+    """One synthetic frame: dict with every tensor `batch_render_pifu_nerf` needs (B = V = 1).
+
+    Keys mirror the reference call (src/model.py:1102-1120, 313-317, 345-349):
+      img_in (1,3,256,256), feat_geo [(1,64,32,32),(1,8,128,128)], feat_tex (1,8,64,64),
+      cam_in, cam_tar, targets{vert_world, face_world, tar_cam}, sp_data{extrin,kpt3d},
+      src_foreground_mask (1,1,1,256,256), bounds (1,2,3).
+    """
+    g = torch.Generator().manual_seed(seed)
+    verts_np, faces_np = two_hand_mesh(seed)
+    verts = torch.from_numpy(verts_np)[None]
+    faces = torch.from_numpy(faces_np)[None].float()  # reference passes faces as float and calls .long()
+    centre = verts[0].mean(0)
+
+    kpts = []
+    for h in range(2):
+        c = verts[0, h * NV_HAND:(h + 1) * NV_HAND].mean(0)
+        kpts.append(c[None] + 0.03 * torch.randn(21, 3, generator=g))
+    kpt3d = torch.cat(kpts, 0)[None]
+
+    znear, zfar = 0.71, 1.42
+    # source camera: identity extrinsic, principal point at the image centre
+    K_src = torch.eye(4)
+    K_src[0, 0] = K_src[1, 1] = focal_src
+    K_src[0, 2] = K_src[1, 2] = src_hw / 2.0
+    E_src = torch.eye(4)
+    cam_in = {
+        "KRT": (K_src @ E_src)[None], "K": K_src[None], "Rt": E_src[None, :3, :4], "extrin": E_src[None],
+        "znear": znear, "zfar": zfar, "width": src_hw, "height": src_hw, "nml_scale": 100.0,
+    }
+    # target camera: orbit about the scene centre
+    ang = math.radians(orbit_deg)
+    dist = float(centre[2])
+    eye = np.array([centre[0].item() + dist * math.sin(ang), centre[1].item() - 0.02, centre[2].item() - dist * math.cos(ang)])
+    E_tar = torch.from_numpy(look_at_extrinsic(eye, centre.numpy()))
+    K_tar = torch.eye(4)
+    f_tar = focal_src * tar_w / src_hw * 0.9
+    K_tar[0, 0] = K_tar[1, 1] = f_tar
+    K_tar[0, 2] = tar_w / 2.0
+    K_tar[1, 2] = tar_h / 2.0
+    cam_tar = {
+        "K": K_tar[None], "RT": E_tar[None], "KRT": (K_tar @ E_tar)[None],
+        "width": tar_w, "height": tar_h, "nml_scale": 100.0, "znear": znear, "zfar": zfar,
+    }
+    bmin = verts[0].min(0)[0].clone()
+    bmax = verts[0].max(0)[0].clone()
+    bmin[2] -= 0.05
+    bmax[2] += 0.05
+    bounds = torch.stack([bmin, bmax], 0)[None]
+
+    img = torch.rand(1, 3, src_hw, src_hw, generator=g)
+    mask = torch.ones(1, 1, 1, src_hw, src_hw)
+    if half_mask:
+        mask[..., : src_hw // 2 - 9] = 0.0
+    feat_geo = [torch.rand(1, 64, 32, 32, generator=g) * 2 - 1, torch.rand(1, 8, 128, 128, generator=g) * 2 - 1]
+    feat_tex = torch.rand(1, 8, 64, 64, generator=g) * 2 - 1
+    targets = {
+        "vert_world": verts, "face_world": faces,
+        "tar_cam": {"tar_R": E_tar[None, :3, :3], "tar_T": E_tar[None, :3, 3],
+                    "tar_focal": torch.tensor([[f_tar, f_tar]]), "tar_princpt": torch.tensor([[tar_w / 2.0, tar_h / 2.0]])},
+    }
+    frame = {
+        "img_in": img, "feat_geo": feat_geo, "feat_tex": feat_tex, "cam_in": cam_in, "cam_tar": cam_tar,
+        "targets": targets, "sp_data": {"extrin": E_src[None].clone(), "kpt3d": kpt3d},
+        "src_foreground_mask": mask, "bounds": bounds, "hand_type": torch.ones(1, 2),
+    }
+    return to_device(frame, device)
+
+
+def to_device(obj, device):
+    if isinstance(obj, torch.Tensor):
+        return obj.to(device)
+    if isinstance(obj, dict):
+        return {k: to_device(v, device) for k, v in obj.items()}
+    if isinstance(obj, (list, tuple)):
+        return type(obj)(to_device(v, device) for v in obj)
+    return obj
