@@ -1,0 +1,155 @@
+/*
+ * vanerf_hip.h -- C ABI of the MI355X-native VANeRF volume-rendering hot path (libvanerf_hip.so).
+ *
+ * The reference (XuanHuang0/VANeRF) has no FFI of its own: its seam is Python methods on
+ * `class VANeRF(torch.nn.Module)` (src/model.py:604).  Each entry point below replaces the
+ * arithmetic of one of those methods (cited per function); `vanerf_amd/model.py` keeps the
+ * Python signatures and calls these through ctypes.  INTEGRATION.md shows the binding a
+ * maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every `const float*` / `float*` / `int*` below is a DEVICE pointer borrowed from the caller
+ *     (contiguous, fp32 / int32 / uint8); the library allocates nothing that outlives a call
+ *     except the packed-weight handle;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); no entry point
+ *     synchronises the host, all work is enqueued on `stream`;
+ *   - return value: 0 on success, negative on error (message via vanerf_last_error(), thread local);
+ *   - B = V = 1 (one target view, one source view): the non-spconv reference path is
+ *     structurally single-view (src/networks.py:86,94) and evaluates batch items in Python loops.
+ */
+#ifndef VANERF_HIP_H
+#define VANERF_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VANERF_ABI_VERSION 1
+
+#define VANERF_OK 0
+#define VANERF_EINVAL (-22)
+#define VANERF_ENOMEM (-12)
+#define VANERF_EHIP (-5)
+
+#define VANERF_NV 1558      /* vertices: 2 x (778 + 1 seal vertex), src/networks.py:25 */
+#define VANERF_NV_HAND 779
+#define VANERF_NKPT 42
+#define VANERF_PE_LEVELS 3  /* sp_level, configs/vanerf.json:50 */
+
+/* Host pointers to the per-sample network weights in the reference's state_dict layout
+ * (row-major [out][in], Conv1d k=1 weights with the trailing 1 dropped).  Weight-normed layers
+ * (src/utils.py:674-675) are passed as (v, g): the packer folds W = g * v / ||v||_row.          */
+typedef struct {
+    const float* geo_at0_w1;   /* [10][196]  geo_vis_fusion.fconv_at.0.weight   (src/networks.py:47-52) */
+    const float* geo_at0_w2;   /* [3][10]    geo_vis_fusion.fconv_at.2.weight */
+    const float* geo_ated0_w1; /* [64][196]  geo_vis_fusion.fconv_ated.0.weight (54-58) */
+    const float* geo_ated0_w2; /* [64][64]   geo_vis_fusion.fconv_ated.2.weight */
+    const float* geo_at1_w1;   /* [10][28]   geo_vis_fusion.fconv_at1.0.weight  (60-65) */
+    const float* geo_at1_w2;   /* [3][10] */
+    const float* geo_ated1_w1; /* [8][28]    geo_vis_fusion.fconv_ated1.0.weight (67-71) */
+    const float* geo_ated1_w2; /* [8][8] */
+    /* mlp_geo (src/utils.py:609-649): layers1 = [358->128, 128->128, 136->120, 120->64], layers2 = [128->64, 64->64, 64->2] */
+    const float* l1_v[3];      /* weight_v of layers1.{0,1,2}: [128][358], [128][128], [120][136] */
+    const float* l1_g[3];      /* weight_g: [128], [128], [120] */
+    const float* l1_b[3];      /* bias */
+    const float* l1_w3;        /* [64][120] layers1.3 (plain) */
+    const float* l1_b3;        /* [64] */
+    const float* l2_v[2];      /* layers2.{0,1}: [64][128], [64][64] */
+    const float* l2_g[2];
+    const float* l2_b[2];
+    const float* l2_w2;        /* [2][64] layers2.2 (plain) */
+    const float* l2_b2;        /* [2] */
+    const float* ibr_w;        /* [24][128] ibr_compress_gfeat (src/model.py:633-636) */
+    const float* ibr_b;        /* [24] */
+    const float* tex_at_w1;    /* [96][96]  tex_vis_fusion.fconv_at.0.weight (src/networks.py:230-235) */
+    const float* tex_at_w2;    /* [6][96] */
+    const float* tex_w1;       /* [96][96]  tex_vis_fusion.fconv.0.weight (224-228) */
+    const float* tex_w2;       /* [40][96]  (only rows 0..2 reach the image at V = 1: src/model.py:1613,1635) */
+    float sigmoid_beta;        /* VANeRF.sigmoid_beta (src/model.py:614); clamped to >= 2e-3 as in sdf_activation (880) */
+} VanerfWeightTable;
+
+/* Per-source-frame inputs of the per-sample networks (all device pointers, fp32). */
+typedef struct {
+    const float* geo0;      /* [h0][w0][64] feat_geo[0], channel-last          (src/model.py:826, 971) */
+    const float* geo1;      /* [h1][w1][8]  feat_geo[1], channel-last */
+    const float* tex;       /* [ht][wt][8]  feat_tex, channel-last             (src/model.py:919, 972) */
+    const float* img;       /* [hi][wi][4]  source image rgb + pad             (src/model.py:906) */
+    const float* mask;      /* [hi][wi]     src_foreground_mask                (src/model.py:800) */
+    int h0, w0, h1, w1, ht, wt, hi, wi;
+    const float* verts;     /* [NV][4] vert_world xyz + pad */
+    const float* vfeat0;    /* [NV][64] feat_sample(feat_geo[0], vert_xy) * vert_vis   (src/networks.py:83, 29) */
+    const float* vfeat1;    /* [NV][8]  feat_sample(feat_geo[1], vert_xy) * vert_vis   (src/networks.py:96) */
+    const float* vfeat_tex; /* [NV][32] [img3 | tex8 | gf18 | 0 0 0] * vert_vis        (src/networks.py:270-279) */
+    const float* vert_vis;  /* [NV]     {0,1}                                          (mesh_util.py:284-318) */
+    const float* kpt_cam;   /* [42][4]  key points in source-camera coordinates (src/spatial.py:84) */
+    float KRT[12];          /* source view K*[R|t], rows 0..2 (src/model.py:780) */
+    float extrin[12];       /* source view [R|t]                (src/spatial.py:71-72) */
+    float width, height, znear, zfar; /* cam_in (src/model.py:313-317) */
+    float invalid_sdf;      /* 0.1 / nml_scale (src/model.py:1144) */
+    float pe_scale, pe_inv_2sigma2; /* sp_args.scale, 1/(2 sigma^2) (src/spatial.py:110-113) */
+} VanerfFrame;
+
+typedef struct VanerfWeights VanerfWeights; /* opaque device-resident packed weights */
+
+int vanerf_abi_version(void);
+const char* vanerf_last_error(void);
+
+/* Packs the weight table into MFMA fragment order on the device.  mode: 0 = fp32 (exact, v_mfma_f32_32x32x2_f32). */
+int vanerf_weights_pack(const VanerfWeightTable* w, int mode, VanerfWeights** out);
+int vanerf_weights_free(VanerfWeights* w);
+/* Host-only view of the packed fragment stream (no GPU touched): out[cap] or NULL to query the size; offsets[20]. */
+int vanerf_weights_pack_host(const VanerfWeightTable* w, float* out, int64_t cap, int64_t* n_out, unsigned* offsets);
+
+/* a1-a4  Pixel grid, ray generation, bbox clipping, coarse depths (src/model.py:1191-1238, 1496-1570).
+ *   grid: x = x0 + ix*step, y = y0 + iy*step for iy < ny (outer), ix < nx (inner); R = nx*ny rays
+ *   invK_T[9]: inverse(K[:3,:3]) transposed, row-major (host computed, as th.inverse at model.py:1208)
+ *   RT[12]: target [R|t] rows 0..2;  bounds[6] = {min xyz, max xyz} (host values)
+ *   t_lin[S]: th.linspace(0, 1, S) (device; computed by the caller so that it is bit-identical to torch's)
+ *   outputs: index[R] (int64 pixel index x + y*W), rays_d[R][3], cam_pos[3] (device), near[R], far[R], hit[R] (u8),
+ *            z[R][S] coarse depths (uniform=True: t_lin; else stratified with jitter[R][S] in [0,1) drawn by the caller) */
+int vanerf_ray_setup(int x0, int y0, int step, int nx, int ny, int width, const float* invK_T, const float* RT,
+                     float znear, float zfar, const float* bounds, int S, const float* t_lin, const float* jitter,
+                     int64_t* index, float* rays_d, float* cam_pos, float* near, float* far, uint8_t* hit, float* z,
+                     void* stream);
+
+/* eval_pts = cam_pos + dir * z (src/model.py:1234-1235).  pts[R*S][3]. */
+int vanerf_sample_points(const float* rays_d, const float* cam_pos, const float* z, int R, int S, float* pts, void* stream);
+
+/* a6  get_visibility (mesh_util.py:284-318): vert_xy01[NV][2], vert_z01[NV], faces[NF][3] int32 -> vert_vis[NV];
+ *     pix_to_face[S*S] int32 is scratch (may be NULL only if `scratch` given).                                          */
+int vanerf_vertex_visibility(const float* vert_xy01, const float* vert_z01, int nv, const int32_t* faces, int nf,
+                             int raster, int32_t* pix_to_face, float* vert_vis, void* stream);
+
+/* a6  cal_vis_sdf_batch (mesh_util.py:498-524): signed distance, closest face, interpolated visibility.
+ *     verts[NV][3], faces[NF][3] int32, vert_vis[NV], pts[N][3] -> sdf[N], vis[N] (u8), face[N] (int32, may be NULL)     */
+int vanerf_mesh_query(const float* verts, int nv, const int32_t* faces, int nf, const float* vert_vis,
+                      const float* pts, int64_t n, float* sdf, uint8_t* vis, int32_t* face, void* stream);
+
+/* a10 knn_points K=1 (src/networks.py:28): verts[NV][4], pts[N][3] -> idx[N] int32 (first minimum). */
+int vanerf_knn1(const float* verts4, int nv, const float* pts, int64_t n, int32_t* idx, void* stream);
+
+/* a7-a15  VANeRF.query + eval_func for N samples (src/model.py:748-957, 1140-1160), n_views = 1:
+ *     pts[N][3], query_sdf[N], query_vis[N] (u8), noise[N] or NULL (rand_noise_std draws, model.py:1156)
+ *     -> out[N][5] = [alpha, sdf, r, g, b];  valid[N] (u8, may be NULL);  knn_idx[N] (int32, may be NULL)                */
+int vanerf_query_samples(const VanerfWeights* w, const VanerfFrame* frame, const float* pts, const float* query_sdf,
+                         const uint8_t* query_vis, const float* noise, int64_t n, float* out, uint8_t* valid,
+                         int32_t* knn_idx, void* stream);
+
+/* a16  sdf_activation + rgba2out (src/model.py:879-882, 1464-1494):
+ *     rgba[R][S][5], z[R][S], mesh_sdf[R][S] -> color[R][3], depth[R], alpha[R], sdf[R], contrib[R][S] (may be NULL)      */
+int vanerf_composite(const float* rgba, const float* z, const float* mesh_sdf, int R, int S, float beta,
+                     float* color, float* depth, float* alpha, float* sdf, float* contrib, void* stream);
+
+/* a17  importance_sample + sort-merge (src/model.py:1424-1462, 1301-1307):
+ *     contrib[R][Sc], z[R][Sc], u[R][Sf] (random draws) or NULL with t_lin[Sf] = th.linspace(0, 1, Sf) (uniform=True) ->
+ *     z_new[R][Sf], z_fine[R][Sc+Sf] (sorted), src[R][Sc+Sf] int32 (>= 0: coarse sample id, < 0: ~(new sample id)),
+ *     idx[R][Sf] int32 searchsorted index after clamping (may be NULL)                                                   */
+int vanerf_importance_merge(const float* contrib, const float* z, const float* u, const float* t_lin, int R, int Sc, int Sf,
+                            float* z_new, float* z_fine, int32_t* src, int32_t* idx, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VANERF_HIP_H */

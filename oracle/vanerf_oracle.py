@@ -285,7 +285,10 @@ def importance_sample(contrib, z, sample_per_ray, uniform=True, u=None, return_i
     `u` replaces th.rand when uniform=False (training RNG drawn on the host)."""
     assert contrib.shape[-1] == z.shape[-1] - 1
     contrib = contrib + 1e-5
-    pdf = contrib / contrib.sum(-1, keepdim=True)
+    # The reference's float .sum() has an implementation-defined order; accumulate in fp64 and round once so the
+    # result (and the integer searchsorted indices that depend on it) is order independent.  CPU cumsum already
+    # accumulates in fp64 (at::acc_type<float, /*is_cuda=*/false>) and rounds each prefix to fp32.
+    pdf = contrib / contrib.double().sum(-1, keepdim=True).float()
     cdf = torch.cumsum(pdf, -1)
     cdf = torch.cat([torch.zeros_like(cdf[:, :, :1]), cdf], 2)
     if uniform:
@@ -465,7 +468,7 @@ def batch_render(sd, frame, level, stride_xy, sample_per_ray_c=64, sample_per_ra
     if grids is None:
         grids, index = pixel_grid(width, height, level, stride_xy)
         out_w, out_h = width // st, height // st
-    else:
+    else:  # explicit pixel list (tests at sizes / strides the reference's grid cannot express)
         index = grids[..., 0] + grids[..., 1] * width
         out_h, out_w = frame["out_hw"]
     cam_rays, cam_pos, znear_rays, zfar_rays, hit = generate_rays(grids, cam_tar, frame["bounds"], znear, zfar)

@@ -38,3 +38,17 @@ def golden():
 @pytest.fixture(scope="session")
 def hot_weights():
     return load_golden("weights_hot")
+
+
+def assert_close_frac(got, ref, tol, max_outlier_frac=1e-3, what=""):
+    """|got - ref| <= tol for all but a `max_outlier_frac` fraction of the elements (at least one element allowed).
+
+    The renderer contains arg-min / threshold decisions (1-NN vertex, closest face, inside test, visibility >= 0.1,
+    searchsorted) that turn a last-bit difference of a sample position into an O(1) change of that one sample.
+    The reference itself has this property (its CPU and CUDA runs differ the same way), so whole-image comparisons
+    bound the fraction of affected pixels instead of demanding that none exists."""
+    err = (got.float() - ref.float()).abs().flatten()
+    bad = int((err > tol).sum())
+    allowed = max(1, int(max_outlier_frac * err.numel()))
+    assert bad <= allowed, f"{what}: {bad}/{err.numel()} elements above {tol} (max err {err.max().item():.3e}, allowed {allowed})"
+    return err.max().item(), bad

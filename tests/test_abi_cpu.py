@@ -1,0 +1,73 @@
+"""CPU-side checks of the C ABI: the library loads, exports every symbol include/vanerf_hip.h declares, validates
+its arguments without touching a GPU, and the weight packer places every weight exactly once."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def ffi():
+    from vanerf_amd import build
+    build.build()  # in-tree hipcc build (cross-compiles gfx950 without a GPU); no-op when up to date
+    from vanerf_amd import _ffi
+    return _ffi
+
+
+def test_exports_match_header(ffi):
+    hdr = open(os.path.join(REPO, "include", "vanerf_hip.h")).read()
+    declared = set(re.findall(r"\b(vanerf_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    assert declared == set(ffi.EXPORTS)
+    for name in declared:
+        assert hasattr(ffi.lib, name), name
+    assert ffi.lib.vanerf_abi_version() == 1
+
+
+def test_error_convention(ffi):
+    # null arguments: negative return code + message, no exception across the ABI, no GPU touched
+    rc = ffi.lib.vanerf_composite(None, None, None, 4, 4, 0.1, None, None, None, None, None, None)
+    assert rc == -22 and b"null" in ffi.lib.vanerf_last_error()
+    rc = ffi.lib.vanerf_knn1(ctypes.c_void_p(8), 0, ctypes.c_void_p(8), 1, ctypes.c_void_p(8), None)
+    assert rc == -22 and b"nv=0" in ffi.lib.vanerf_last_error()
+    with pytest.raises(ffi.VanerfError):
+        ffi.check(rc)
+
+
+def test_packer_places_every_weight_once(ffi, hot_weights):
+    from vanerf_amd import renderer
+    sd = dict(hot_weights)
+    stream, offs = renderer.pack_weights_host(sd)
+    assert len(offs) == 20 and offs[0] == 0 and all(b > a for a, b in zip(offs, offs[1:]))
+
+    def layer(i):
+        end = offs[i + 1] if i + 1 < len(offs) else stream.numel() - 2 * 64 * 4
+        return stream[offs[i]:end]
+
+    def eff(prefix):
+        v, g = sd[prefix + "weight_v"], sd[prefix + "weight_g"]
+        return torch.cat([(v * (g / v.norm(2, dim=1, keepdim=True))).flatten(), sd[prefix + "bias"]])
+
+    expect = {
+        0: sd["geo_vis_fusion.fconv_at.0.weight"].flatten(), 3: sd["geo_vis_fusion.fconv_ated.2.weight"].flatten(),
+        8: eff("mlp_geo.layers1.layers.0.linear."), 9: eff("mlp_geo.layers1.layers.1.linear."), 10: eff("mlp_geo.layers1.layers.2.linear."),
+        11: torch.cat([sd["mlp_geo.layers1.layers.3.linear.weight"].flatten(), sd["mlp_geo.layers1.layers.3.linear.bias"]]),
+        12: eff("mlp_geo.layers2.layers.0.linear."), 15: torch.cat([sd["ibr_compress_gfeat.weight"].flatten(), sd["ibr_compress_gfeat.bias"]]),
+        16: sd["tex_vis_fusion.fconv_at.0.weight"].flatten(), 19: sd["tex_vis_fusion.fconv.2.weight"][:3].flatten(),
+    }
+    for i, w in expect.items():
+        got = layer(i)
+        got = torch.sort(got[got != 0])[0]
+        want = torch.sort(w[w != 0])[0]
+        assert got.numel() == want.numel(), (i, got.numel(), want.numel())
+        assert (got - want).abs().max() <= 1e-6 * max(1.0, want.abs().max().item()), i
+
+
+def test_product_path_has_no_cpu_fallback(ffi):
+    from vanerf_amd import renderer
+    with pytest.raises(ValueError):
+        renderer.knn1(torch.zeros(4, 4), torch.zeros(2, 3))  # CPU tensors are refused, never silently computed

@@ -1,0 +1,277 @@
+"""Parity of the HIP path (through the C ABI, libvanerf_hip.so) against the CPU oracle on the same seeded inputs
+and against the golden fixtures captured from the reference.  Needs a real MI355X: `pytest -m gpu`.
+
+Bars (BASELINE.json north_star): integer outputs (pixel index, 1-NN index, searchsorted index, closest face,
+visibility flags) bit-exact given identical inputs; floats within 1e-4 abs (RGB, per-sample alpha/sdf/colour);
+sigma is compared relative to its scale 1/beta (it reaches 1/beta = 10 at the default beta = 0.1)."""
+import math
+
+import pytest
+import torch
+
+from oracle import vanerf_oracle as orc
+from tests.conftest import assert_close_frac
+from vanerf_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def R():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU (torch.cuda.is_available() is False)")
+    from vanerf_amd import renderer
+    return renderer
+
+
+@pytest.fixture(scope="module")
+def sd_full(golden, hot_weights):
+    from tests.test_oracle_golden import _texframe_weights
+    sd = dict(hot_weights)
+    sd.update(_texframe_weights(golden))
+    return sd
+
+
+def dev(t):
+    return t.cuda()
+
+
+def _frame(seed, hw, orbit=8.0, half=False, tar_w=None):
+    return synth.make_frame(seed=seed, tar_h=hw, tar_w=tar_w or hw, orbit_deg=orbit, half_mask=half)
+
+
+def _frame_data(R, sd, frame):
+    fd = synth.to_device(frame, "cuda")
+    sdd = {k: v.cuda() for k, v in sd.items() if k.startswith("tex_vis_fusion.")}
+    return R.FrameData(sdd, fd["img_in"], fd["feat_geo"], fd["feat_tex"], fd["src_foreground_mask"], fd["cam_in"], fd["targets"], fd["sp_data"])
+
+
+def _points_near_mesh(frame, n, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    v = frame["targets"]["vert_world"][0]
+    p = v[torch.randint(0, v.shape[0], (n,), generator=g)] + 0.012 * torch.randn(n, 3, generator=g)
+    p[: n // 16] += torch.tensor([0.5, 0.0, 0.0])  # off-image samples
+    p[n // 16: n // 8] = v[torch.randint(0, v.shape[0], (n // 8 - n // 16,), generator=g)]  # exactly on vertices (distance ties)
+    return p.contiguous()
+
+
+def test_knn1_bit_exact(R):
+    frame = _frame(3, 64)
+    p = _points_near_mesh(frame, 20000)
+    v = frame["targets"]["vert_world"][0]
+    v4 = torch.cat([v, torch.zeros(v.shape[0], 1)], 1).contiguous()
+    got = R.knn1(dev(v4), dev(p)).cpu().long()
+    assert torch.equal(got, orc.knn1(p, v))
+
+
+def test_vertex_visibility_bit_exact(R):
+    for seed, orbit in ((3, 8.0), (5, 70.0)):
+        frame = _frame(seed, 64, orbit)
+        xy01, z01 = orc.source_vert_xyz01(frame["targets"]["vert_world"], frame["cam_in"])
+        faces = frame["targets"]["face_world"][0].to(torch.int32)
+        want = orc.vertex_visibility(xy01[0], z01[0], faces)[:, 0]
+        got = R.vertex_visibility(dev(xy01[0].contiguous()), dev(z01[0, :, 0].contiguous()), dev(faces)).cpu()
+        assert torch.equal(got, want)
+        assert 0.2 < want.mean() < 0.8
+
+
+def test_mesh_query_bit_exact(R):
+    frame = _frame(3, 64)
+    p = _points_near_mesh(frame, 30000, seed=1)
+    verts = frame["targets"]["vert_world"]
+    faces = frame["targets"]["face_world"].long()
+    xy01, z01 = orc.source_vert_xyz01(verts, frame["cam_in"])
+    sdf, vis, vert_vis, cface = orc.cal_vis_sdf_batch(verts, faces, p[None], xy01, z01)
+    f32 = faces[0].to(torch.int32)
+    g_sdf, g_vis, g_face = R.mesh_query(dev(verts[0].contiguous()), dev(f32), dev(vert_vis[0, :, 0].contiguous()), dev(p), want_face=True)
+    assert torch.equal(g_sdf.cpu(), sdf[0])  # bit-exact floats: same IEEE operations in the same order
+    assert torch.equal(g_vis.cpu().bool(), vis[0, :, 0])
+    assert torch.equal(faces[0][g_face.cpu().long()], cface[0])
+    assert 0.05 < (sdf < 0).float().mean() < 0.95
+
+
+def test_ray_setup(R):
+    for seed, hw, tw, step, off in ((3, 64, 64, 8, (3, 5)), (11, 512, 334, 2, (1, 0))):
+        frame = _frame(seed, hw, 15.0, tar_w=tw)
+        cam = frame["cam_tar"]
+        level = int(math.log2(step)) + 1
+        grids, index = orc.pixel_grid(cam["width"], cam["height"], level, torch.tensor([[list(off)]]))
+        rays, pos, near, far, hit = orc.generate_rays(grids, cam, frame["bounds"], cam["znear"], cam["zfar"])
+        nx, ny = cam["width"] // step, cam["height"] // step
+        S = 16
+        got = R.ray_setup(cam, frame["bounds"], off[0], off[1], step, nx, ny, S, device="cuda")
+        assert torch.equal(got["index"].cpu(), index[0])  # integer pixel indices: bit-exact
+        assert (got["rays_d"].cpu() - rays[0]).abs().max() <= 1e-6
+        assert (got["cam_pos"].cpu() - pos[0, 0]).abs().max() <= 1e-6
+        assert torch.equal(got["hit"].cpu().bool(), hit[0, :, 0])
+        assert (got["near"].cpu() - near[0, :, 0]).abs().max() <= 2e-6 and (got["far"].cpu() - far[0, :, 0]).abs().max() <= 2e-6
+        z = near + (far - near) * torch.linspace(0.0, 1.0, steps=S)[None, None]
+        assert (got["z"].cpu() - z[0]).abs().max() <= 2e-6
+        assert 0.1 < hit.float().mean() < 1.0
+        pts = R.sample_points(got["rays_d"], got["cam_pos"], got["z"]).cpu()
+        want = (got["cam_pos"].cpu()[None, None] + got["rays_d"].cpu()[:, None] * got["z"].cpu()[..., None]).view(-1, 3)
+        assert torch.equal(pts, want)  # same inputs, same IEEE mul/add: bit-exact
+
+
+@pytest.mark.parametrize("beta", [0.1, 0.01, 1e-3])
+def test_composite(R, beta):
+    g = torch.Generator().manual_seed(4)
+    Rn, S = 500, 128
+    rgba = torch.rand(Rn, S, 5, generator=g)
+    rgba[..., 0] = torch.relu(torch.randn(Rn, S, generator=g)) * 0.05
+    z = torch.sort(torch.rand(Rn, S, generator=g) * 0.3 + 0.8, -1)[0]
+    z[:7] = z[:7, :1]  # degenerate rays (near == far)
+    msdf = torch.randn(Rn, S, generator=g) * 0.02
+    sd = {"sigmoid_beta": torch.tensor([beta])}
+    color, depth, alpha, contrib, sdf = orc.rgba2out(sd, rgba[None], z[None], msdf[None, ..., None])
+    gc, gd, ga, gcon, gs = R.composite(dev(rgba), dev(z), dev(msdf), beta)
+    for got, want in ((gc, color), (gd, depth), (ga, alpha), (gcon, contrib), (gs, sdf)):
+        assert (got.cpu() - want[0]).abs().max() <= 2e-5
+
+
+def test_importance_merge_bit_exact_idx(R, golden):
+    g = torch.Generator().manual_seed(5)
+    Rn, S = 3000, 64
+    contrib = torch.rand(Rn, S, generator=g) ** 6
+    contrib[:10] = 0.0
+    contrib[10:20, 30] = 1.0
+    z = torch.sort(torch.rand(Rn, S, generator=g) * 0.3 + 0.8, -1)[0]
+    z[20:25] = z[20:25, :1]
+    z_mid = 0.5 * (z[:, 1:] + z[:, :-1])
+    want, ip, ix = orc.importance_sample(contrib[None, :, 1:-1], z_mid[None], S, uniform=True, return_idx=True)
+    z_new, z_fine, src, idx = R.importance_merge(dev(contrib), dev(z), S, want_idx=True)
+    assert torch.equal(idx.cpu().long(), ix[0])  # searchsorted indices: bit-exact
+    assert (z_new.cpu() - want[0]).abs().max() <= 1e-6
+    merged = torch.sort(torch.cat([z, want[0]], -1), -1)[0]
+    assert (z_fine.cpu() - merged).abs().max() <= 1e-6
+    zf = z_fine.cpu()
+    assert (zf[:, 1:] >= zf[:, :-1]).all()
+    s = src.cpu().long()
+    from_coarse = s >= 0
+    assert (from_coarse.sum(1) == S).all()
+    assert torch.equal(zf[from_coarse].view(Rn, S), z) and torch.equal(torch.sort(zf[~from_coarse].view(Rn, S), -1)[0], torch.sort(z_new.cpu(), -1)[0])
+    # random u (training): unsorted draws
+    u = torch.rand(Rn, 32, generator=g)
+    want_u = orc.importance_sample(contrib[None, :, 1:-1], z_mid[None], 32, uniform=False, u=u[None])
+    z_new_u, z_fine_u, _ = R.importance_merge(dev(contrib), dev(z), 32, u=dev(u))
+    assert (z_new_u.cpu() - want_u[0]).abs().max() <= 1e-6
+    assert (z_fine_u.cpu() - torch.sort(torch.cat([z, want_u[0]], -1), -1)[0]).abs().max() <= 1e-6
+    # the golden vector from the reference (16 samples)
+    gi = golden("importance")
+    zn, zf2, _, idx2 = R.importance_merge(dev(gi["contrib"][0].contiguous()), dev(gi["z"][0].contiguous()), 16, want_idx=True)
+    # last column (u = 1.0) is a tie in the reference itself, see tests/test_oracle_golden.py::test_importance_sample
+    assert torch.equal(idx2.cpu().long()[:, :-1], gi["idx"][0][:, :-1]) and (zn.cpu() - gi["z_samples"][0])[:, :-1].abs().max() <= 1e-6
+    assert (zf2.cpu() - gi["merged"][0]).abs().max() <= (gi["z_mid"][0, :, -1] - gi["z_mid"][0, :, -2]).max()
+
+
+def _query_both(R, sd, frame, pts, view=None):
+    verts = frame["targets"]["vert_world"]
+    xy01, z01 = orc.source_vert_xyz01(verts, frame["cam_in"])
+    q_sdf, q_vis, vert_vis, _ = orc.cal_vis_sdf_batch(verts, frame["targets"]["face_world"].long(), pts[None], xy01, z01)
+    view = view if view is not None else torch.nn.functional.normalize(torch.ones_like(pts), dim=-1)[None]
+    want = {}
+    rgba, valid = orc.query(sd, pts[None], frame["cam_in"], frame["targets"], frame["feat_geo"], frame["feat_tex"], vert_vis, q_vis, q_sdf,
+                            frame["sp_data"], frame["img_in"], view, frame["src_foreground_mask"], want=want)
+    ref = orc.eval_func(sd, rgba, valid, frame["cam_in"]["nml_scale"])[0]
+    fdat = _frame_data(R, sd, frame)
+    w = R.PackedWeights(sd)
+    got, gvalid, gknn = R.query_samples(w, fdat, dev(pts), dev(q_sdf[0].contiguous()), dev(q_vis[0, :, 0].to(torch.uint8).contiguous()),
+                                        want_valid=True, want_knn=True)
+    return ref, valid[0, :, 0], got.cpu(), gvalid.cpu().bool(), gknn.cpu().long(), fdat, vert_vis
+
+
+@pytest.mark.parametrize("seed,half", [(3, False), (5, True)])
+def test_query_samples_vs_oracle(R, sd_full, seed, half):
+    frame = _frame(seed, 64, 8.0, half)
+    pts = _points_near_mesh(frame, 4096 + 17, seed=2)
+    ref, valid, got, gvalid, gknn, fdat, vert_vis = _query_both(R, sd_full, frame, pts)
+    assert torch.equal(gknn, orc.knn1(pts, frame["targets"]["vert_world"][0]))  # 1-NN index: bit-exact
+    assert torch.equal(gvalid, valid)
+    assert torch.equal(fdat.vert_vis.cpu(), vert_vis[0, :, 0])
+    err = (got - ref).abs()
+    print("query_samples max abs err [alpha, sdf, r, g, b]:", err.max(0)[0].tolist(), "alpha>0:", (ref[:, 0] > 0).float().mean().item())
+    assert 0.05 < (ref[:, 0] > 0).float().mean() < 0.95 and 0.05 < valid.float().mean() < 0.999
+    assert err.max() <= TOL
+    beta = 0.1
+    sig_ref = torch.sigmoid(-(ref[:, 0]) / beta) / beta
+    sig_got = torch.sigmoid(-(got[:, 0]) / beta) / beta
+    assert (sig_ref - sig_got).abs().max() * beta <= TOL
+
+
+def test_query_samples_vs_reference_golden(R, sd_full, golden):
+    """Golden vector produced by the reference's own VANeRF.query (tests/golden/query.npz)."""
+    g = golden("query")
+    frame = synth.make_frame(seed=3, tar_h=64, tar_w=64, half_mask=True)
+    fdat = _frame_data(R, sd_full, frame)
+    assert (fdat.vfeat_tex.cpu()[:, :29] - g["vert_feat29"][0] * g["vert_vis"][0]).abs().max() <= 1e-5
+    w = R.PackedWeights(sd_full)
+    got, gvalid = R.query_samples(w, fdat, dev(g["pts"][0].contiguous()), dev(g["q_sdf"][0].contiguous()),
+                                  dev(g["q_vis"][0, :, 0].to(torch.uint8).contiguous()), want_valid=True)
+    ref = orc.eval_func(sd_full, g["out"], g["valid"], 100.0)[0]
+    assert torch.equal(gvalid.cpu().bool(), g["valid"][0, :, 0])
+    assert (got.cpu() - ref).abs().max() <= TOL
+
+
+@pytest.mark.parametrize("tag,seed,hw,orbit,half", [("pass_8x8_s16", 3, 64, 8.0, False), ("pass_16x16_s24_bvv", 5, 64, 70.0, True),
+                                                     ("pass_64x64_s64", 11, 256, 15.0, False)])
+def test_render_pass_vs_reference_golden(R, sd_full, golden, tag, seed, hw, orbit, half):
+    """Whole pass against the outputs of the reference's batch_render_pifu_nerf (tests/golden/pass_*.npz)."""
+    g = golden(tag)
+    frame = _frame(seed, hw, orbit, half)
+    fdat = _frame_data(R, sd_full, frame)
+    w = R.PackedWeights(sd_full)
+    S, level = int(g["S"]), int(g["level"])
+    step = 2 ** (level - 1)
+    off = g["stride_xy"].long().tolist()
+    n = hw // step
+    cam = frame["cam_tar"]
+    out = R.render_pass(w, fdat, cam, frame["bounds"], off[0], off[1], step, n, n, S, S)
+    for k, gk in (("color", "tex_fg"), ("color_fine", "tex_fg_fine")):
+        got = out[k].cpu().view(n, n, 3).permute(2, 0, 1)
+        err, bad = assert_close_frac(got, g[gk][0], TOL, 1e-3, gk)
+        print(tag, gk, "max abs err", err, "outliers", bad, "psnr", orc.psnr(got, g[gk][0]))
+    for k, gk in (("depth", "depth"), ("alpha", "alpha"), ("depth_fine", "depth_fine"), ("alpha_fine", "alpha_fine"), ("sdf", "sdf")):
+        assert_close_frac(out[k].cpu().view(n, n), g[gk][0], TOL, 1e-3, gk)
+    assert torch.equal(fdat.vert_vis.cpu(), g["vert_vis"][0, :, 0])
+
+
+def test_render_pass_vs_oracle_benchmark_shape(R, sd_full):
+    """A strided slice of the 512x334 @ 64+64 benchmark view against the oracle (the full view takes the oracle ~15 min)."""
+    frame = _frame(11, 512, 15.0, tar_w=334)
+    fdat = _frame_data(R, sd_full, frame)
+    w = R.PackedWeights(sd_full)
+    step, nx, ny = 16, 334 // 16, 512 // 16
+    out = R.render_pass(w, fdat, frame["cam_tar"], frame["bounds"], 5, 3, step, nx, ny, 64, 64)
+    gy, gx = torch.meshgrid(torch.arange(ny) * step + 3, torch.arange(nx) * step + 5, indexing="ij")
+    grids = torch.stack([gx, gy], -1).view(1, -1, 2)
+    fr = dict(frame)
+    fr["out_hw"] = (ny, nx)
+    ref = orc.batch_render(sd_full, fr, 1, None, 64, 64, grids=grids)
+    assert torch.equal(out["index"].cpu(), ref["index"][0])
+    got = out["color_fine"].cpu().view(ny, nx, 3).permute(2, 0, 1)
+    err, bad = assert_close_frac(got, ref["tex_fg_fine"][0], TOL, 1e-3, "tex_fg_fine")
+    print("512x334 slice: max abs err", err, "outliers", bad, "psnr", orc.psnr(got, ref["tex_fg_fine"][0]))
+    assert orc.psnr(got, ref["tex_fg_fine"][0]) > 80.0
+    assert_close_frac(out["depth_fine"].cpu().view(ny, nx), ref["depth_fine"][0], TOL, 1e-3, "depth_fine")
+
+
+def test_full_view_properties(R, sd_full):
+    """Size-independent checks at the full benchmark size (512x334, 64+64 samples)."""
+    frame = _frame(11, 512, 15.0, tar_w=334)
+    fdat = _frame_data(R, sd_full, frame)
+    w = R.PackedWeights(sd_full)
+    full = R.render_pass(w, fdat, frame["cam_tar"], frame["bounds"], 0, 0, 1, 334, 512, 64, 64)
+    torch.cuda.synchronize()
+    assert full["color_fine"].shape == (334 * 512, 3) and torch.isfinite(full["color_fine"]).all()
+    assert torch.equal(full["index"].cpu(), torch.arange(334 * 512))
+    zf = full["z_fine"]
+    assert (zf[:, 1:] >= zf[:, :-1]).all()  # sortedness
+    assert (full["alpha_fine"] <= 1.0 + 1e-5).all() and (full["alpha_fine"] >= 0).all()
+    # determinism / idempotence: a second launch gives identical bits
+    again = R.render_pass(w, fdat, frame["cam_tar"], frame["bounds"], 0, 0, 1, 334, 512, 64, 64)
+    assert torch.equal(full["color_fine"], again["color_fine"])
+    # ray independence: rendering rows [100, 164) alone gives the same bits as the full view's rows
+    part = R.render_pass(w, fdat, frame["cam_tar"], frame["bounds"], 0, 100, 1, 334, 64, 64, 64)
+    assert torch.equal(part["color_fine"], full["color_fine"].view(512, 334, 3)[100:164].reshape(-1, 3))

@@ -1,0 +1,80 @@
+"""ctypes binding of libvanerf_hip.so (the C ABI in include/vanerf_hip.h).
+
+The product path has NO fallback: if the HIP library is missing or fails to load, importing this
+module raises.  Build it with `python -m vanerf_amd.build` (or `__graft_entry__.build()`).
+"""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int64, c_uint, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libvanerf_hip.so")
+ABI_VERSION = 1
+NUM_LAYERS = 20
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(f"{LIB_PATH} not found: the HIP extension is required (run `python -m vanerf_amd.build`)")
+lib = ctypes.CDLL(LIB_PATH)
+
+_FP = c_void_p  # device or host pointer to fp32 data, passed as an integer address
+
+
+class VanerfWeightTable(Structure):
+    _fields_ = [
+        ("geo_at0_w1", _FP), ("geo_at0_w2", _FP), ("geo_ated0_w1", _FP), ("geo_ated0_w2", _FP),
+        ("geo_at1_w1", _FP), ("geo_at1_w2", _FP), ("geo_ated1_w1", _FP), ("geo_ated1_w2", _FP),
+        ("l1_v", _FP * 3), ("l1_g", _FP * 3), ("l1_b", _FP * 3), ("l1_w3", _FP), ("l1_b3", _FP),
+        ("l2_v", _FP * 2), ("l2_g", _FP * 2), ("l2_b", _FP * 2), ("l2_w2", _FP), ("l2_b2", _FP),
+        ("ibr_w", _FP), ("ibr_b", _FP),
+        ("tex_at_w1", _FP), ("tex_at_w2", _FP), ("tex_w1", _FP), ("tex_w2", _FP),
+        ("sigmoid_beta", c_float),
+    ]
+
+
+class VanerfFrame(Structure):
+    _fields_ = [
+        ("geo0", _FP), ("geo1", _FP), ("tex", _FP), ("img", _FP), ("mask", _FP),
+        ("h0", c_int), ("w0", c_int), ("h1", c_int), ("w1", c_int), ("ht", c_int), ("wt", c_int), ("hi", c_int), ("wi", c_int),
+        ("verts", _FP), ("vfeat0", _FP), ("vfeat1", _FP), ("vfeat_tex", _FP), ("vert_vis", _FP), ("kpt_cam", _FP),
+        ("KRT", c_float * 12), ("extrin", c_float * 12),
+        ("width", c_float), ("height", c_float), ("znear", c_float), ("zfar", c_float),
+        ("invalid_sdf", c_float), ("pe_scale", c_float), ("pe_inv_2sigma2", c_float),
+    ]
+
+
+_SIGS = {
+    "vanerf_abi_version": (c_int, []),
+    "vanerf_last_error": (c_char_p, []),
+    "vanerf_weights_pack": (c_int, [POINTER(VanerfWeightTable), c_int, POINTER(c_void_p)]),
+    "vanerf_weights_free": (c_int, [c_void_p]),
+    "vanerf_weights_pack_host": (c_int, [POINTER(VanerfWeightTable), _FP, c_int64, POINTER(c_int64), POINTER(c_uint)]),
+    "vanerf_ray_setup": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, POINTER(c_float), POINTER(c_float), c_float, c_float,
+                                 POINTER(c_float), c_int, _FP, _FP, _FP, _FP, _FP, _FP, _FP, _FP, _FP, c_void_p]),
+    "vanerf_sample_points": (c_int, [_FP, _FP, _FP, c_int, c_int, _FP, c_void_p]),
+    "vanerf_vertex_visibility": (c_int, [_FP, _FP, c_int, _FP, c_int, c_int, _FP, _FP, c_void_p]),
+    "vanerf_mesh_query": (c_int, [_FP, c_int, _FP, c_int, _FP, _FP, c_int64, _FP, _FP, _FP, c_void_p]),
+    "vanerf_knn1": (c_int, [_FP, c_int, _FP, c_int64, _FP, c_void_p]),
+    "vanerf_query_samples": (c_int, [c_void_p, POINTER(VanerfFrame), _FP, _FP, _FP, _FP, c_int64, _FP, _FP, _FP, c_void_p]),
+    "vanerf_composite": (c_int, [_FP, _FP, _FP, c_int, c_int, c_float, _FP, _FP, _FP, _FP, _FP, c_void_p]),
+    "vanerf_importance_merge": (c_int, [_FP, _FP, _FP, _FP, c_int, c_int, c_int, _FP, _FP, _FP, _FP, c_void_p]),
+}
+EXPORTS = tuple(_SIGS)
+
+for _name, (_res, _args) in _SIGS.items():
+    _fn = getattr(lib, _name)  # AttributeError here = the library does not export what the header declares
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+if lib.vanerf_abi_version() != ABI_VERSION:
+    raise ImportError(f"libvanerf_hip.so ABI {lib.vanerf_abi_version()} != binding {ABI_VERSION}: rebuild")
+
+
+class VanerfError(RuntimeError):
+    pass
+
+
+def check(rc):
+    """C ABI convention: 0 = ok, negative = error with a thread-local message."""
+    if rc != 0:
+        msg = lib.vanerf_last_error()
+        raise VanerfError(f"libvanerf_hip error {rc}: {msg.decode() if msg else '?'}")

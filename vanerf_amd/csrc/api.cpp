@@ -1,0 +1,71 @@
+// api.cpp -- ABI bookkeeping: version, thread-local last error, packed-weight handle.
+#include <algorithm>
+#include <cstddef>
+
+#include "common.h"
+
+namespace vanerf {
+static thread_local std::string g_last_error;
+void set_last_error(const char* msg) { g_last_error = msg ? msg : ""; }
+} // namespace vanerf
+
+using namespace vanerf;
+
+extern "C" int vanerf_abi_version(void) { return VANERF_ABI_VERSION; }
+
+extern "C" const char* vanerf_last_error(void) { return g_last_error.c_str(); }
+
+extern "C" int vanerf_weights_pack(const VanerfWeightTable* w, int mode, VanerfWeights** out)
+{
+    return guarded([&] {
+        if (!w || !out) throw_error("vanerf_weights_pack: null argument");
+        if (mode != 0) throw_error("vanerf_weights_pack: mode %d not supported (0 = fp32 MFMA)", mode);
+        const float* const* ptrs = reinterpret_cast<const float* const*>(w);
+        constexpr size_t n_ptrs = offsetof(VanerfWeightTable, sigmoid_beta) / sizeof(const float*);
+        for (size_t i = 0; i < n_ptrs; ++i)
+            if (!ptrs[i]) throw_error("vanerf_weights_pack: weight pointer #%d is null", (int)i);
+        std::vector<float> host;
+        LayerOffsets offs{};
+        pack_weights_host(*w, host, offs);
+        auto* h = new VanerfWeights();
+        h->n_floats = host.size();
+        h->offs = offs;
+        h->mode = mode;
+        h->beta = w->sigmoid_beta < 2e-3f ? 2e-3f : w->sigmoid_beta; // sdf_activation clamp (src/model.py:880)
+        hipError_t e = hipGetDevice(&h->device);
+        if (e == hipSuccess) e = hipMalloc(&h->dev, host.size() * sizeof(float));
+        if (e == hipSuccess) e = hipMemcpy(h->dev, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            if (h->dev) (void)hipFree(h->dev);
+            delete h;
+            hip_check(e, "vanerf_weights_pack: device upload");
+        }
+        *out = h;
+    });
+}
+
+extern "C" int vanerf_weights_free(VanerfWeights* w)
+{
+    return guarded([&] {
+        if (!w) return;
+        if (w->dev) HIP_CHECK(hipFree(w->dev));
+        delete w;
+    });
+}
+
+// Host-only view of the packed stream, used by the CPU tests of the packer (no GPU needed).
+extern "C" int vanerf_weights_pack_host(const VanerfWeightTable* w, float* out, int64_t cap, int64_t* n_out, unsigned* offsets)
+{
+    return guarded([&] {
+        if (!w || !n_out) throw_error("vanerf_weights_pack_host: null argument");
+        std::vector<float> host;
+        LayerOffsets offs{};
+        pack_weights_host(*w, host, offs);
+        *n_out = (int64_t)host.size();
+        if (offsets) std::copy_n(offs.off, (size_t)NUM_LAYERS, offsets);
+        if (out) {
+            if (cap < (int64_t)host.size()) throw_error("vanerf_weights_pack_host: buffer too small");
+            std::copy(host.begin(), host.end(), out);
+        }
+    });
+}

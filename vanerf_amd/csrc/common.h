@@ -1,0 +1,76 @@
+// common.h -- error plumbing shared by the translation units of libvanerf_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/vanerf_hip.h"
+#include "layer_spec.h"
+
+namespace vanerf {
+
+struct Error : std::runtime_error {
+    int code;
+    Error(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+[[noreturn]] inline void throw_error(const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    throw Error(VANERF_EINVAL, buf);
+}
+
+inline void hip_check(hipError_t e, const char* what)
+{
+    if (e != hipSuccess) {
+        char buf[512];
+        snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
+        throw Error(VANERF_EHIP, buf);
+    }
+}
+#define HIP_CHECK(x) ::vanerf::hip_check((x), #x)
+
+void set_last_error(const char* msg);
+
+// Runs `fn`, converts C++ exceptions into the C ABI's negative return codes (never throws across the ABI).
+template <class F>
+int guarded(F&& fn) noexcept
+{
+    try {
+        fn();
+        return VANERF_OK;
+    } catch (const Error& e) {
+        set_last_error(e.what());
+        return e.code;
+    } catch (const std::bad_alloc&) {
+        set_last_error("out of host memory");
+        return VANERF_ENOMEM;
+    } catch (const std::exception& e) {
+        set_last_error(e.what());
+        return VANERF_EINVAL;
+    } catch (...) {
+        set_last_error("unknown error");
+        return VANERF_EINVAL;
+    }
+}
+
+void pack_weights_host(const VanerfWeightTable& w, std::vector<float>& out, LayerOffsets& offs);
+
+} // namespace vanerf
+
+struct VanerfWeights {
+    float* dev = nullptr;   // packed fragment streams
+    size_t n_floats = 0;
+    vanerf::LayerOffsets offs{};
+    int mode = 0;
+    float beta = 0.1f;
+    int device = 0;
+};

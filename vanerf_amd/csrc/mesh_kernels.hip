@@ -1,0 +1,261 @@
+// mesh_kernels.hip -- mesh-geometry inputs of the per-sample networks:
+//   cal_vis_sdf_batch   src/lib/dataset/mesh_util.py:498-524 (kaolin point_to_mesh_distance / check_sign)
+//   get_visibility      src/lib/dataset/mesh_util.py:284-318 (pytorch3d rasterize_meshes)
+//   knn_points (K=1)    src/networks.py:28
+// The arithmetic is the operation-for-operation twin of oracle/mesh_oracle.c (third-party semantics, parity
+// unpinned against the reference; bit-exact against the oracle).  Built with -ffp-contract=off.
+#include "common.h"
+
+using namespace vanerf;
+
+namespace {
+
+struct f3 { float x, y, z; };
+__device__ __forceinline__ f3 sub3(f3 a, f3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ float dot3(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+__device__ __forceinline__ f3 madd3(f3 a, f3 d, float t) { return {a.x + d.x * t, a.y + d.y * t, a.z + d.z * t}; }
+
+__device__ __forceinline__ float point_tri_dist2(f3 p, f3 a, f3 b, f3 c)
+{
+    const f3 ab = sub3(b, a), ac = sub3(c, a), ap = sub3(p, a);
+    const float d1 = dot3(ab, ap), d2 = dot3(ac, ap);
+    f3 q;
+    if (d1 <= 0.0f && d2 <= 0.0f) {
+        q = a;
+    } else {
+        const f3 bp = sub3(p, b);
+        const float d3 = dot3(ab, bp), d4 = dot3(ac, bp);
+        if (d3 >= 0.0f && d4 <= d3) {
+            q = b;
+        } else {
+            const float vc = d1 * d4 - d3 * d2;
+            if (vc <= 0.0f && d1 >= 0.0f && d3 <= 0.0f) {
+                q = madd3(a, ab, d1 / (d1 - d3));
+            } else {
+                const f3 cp = sub3(p, c);
+                const float d5 = dot3(ab, cp), d6 = dot3(ac, cp);
+                if (d6 >= 0.0f && d5 <= d6) {
+                    q = c;
+                } else {
+                    const float vb = d5 * d2 - d1 * d6;
+                    if (vb <= 0.0f && d2 >= 0.0f && d6 <= 0.0f) {
+                        q = madd3(a, ac, d2 / (d2 - d6));
+                    } else {
+                        const float va = d3 * d6 - d5 * d4;
+                        const float e1 = d4 - d3, e2 = d5 - d6;
+                        if (va <= 0.0f && e1 >= 0.0f && e2 >= 0.0f) {
+                            q = madd3(b, sub3(c, b), e1 / (e1 + e2));
+                        } else {
+                            const float den = 1.0f / ((va + vb) + vc);
+                            const float v = vb * den, w = vc * den;
+                            q.x = (a.x + ab.x * v) + ac.x * w;
+                            q.y = (a.y + ab.y * v) + ac.y * w;
+                            q.z = (a.z + ab.z * v) + ac.z * w;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    const f3 r = sub3(p, q);
+    return dot3(r, r);
+}
+
+// canonical (index-ordered) edge function in the (y,z) plane, see oracle/mesh_oracle.c:edge_side
+__device__ __forceinline__ bool edge_side(f3 va, f3 vb, int ia, int ib, float qy, float qz, float& E)
+{
+    const bool fwd = ia < ib;
+    const f3 lo = fwd ? va : vb, hi = fwd ? vb : va;
+    float e = (hi.y - lo.y) * (qz - lo.z) - (hi.z - lo.z) * (qy - lo.y);
+    if (!fwd) e = -e;
+    E = e;
+    return (e > 0.0f) || (e == 0.0f && fwd);
+}
+
+constexpr int MQ_BLOCK = 256;
+constexpr int MQ_TILE = 512; // triangles staged per LDS tile
+
+__global__ __launch_bounds__(MQ_BLOCK) void mesh_query_kernel(const float* __restrict__ V, const int32_t* __restrict__ F, int nf,
+                                                              const float* __restrict__ vert_vis, const float* __restrict__ P,
+                                                              long long n, float* __restrict__ sdf, uint8_t* __restrict__ vis,
+                                                              int32_t* __restrict__ face)
+{
+    __shared__ float s_tri[MQ_TILE][9];
+    __shared__ int s_idx[MQ_TILE][3];
+    const long long i = (long long)blockIdx.x * MQ_BLOCK + threadIdx.x;
+    const bool live = i < n;
+    const long long ii = live ? i : n - 1;
+    const f3 p = {P[3 * ii], P[3 * ii + 1], P[3 * ii + 2]};
+    float best = INFINITY;
+    int bf = 0, cnt = 0;
+    for (int f0 = 0; f0 < nf; f0 += MQ_TILE) {
+        const int m = min(MQ_TILE, nf - f0);
+        __syncthreads();
+        for (int k = threadIdx.x; k < m * 3; k += MQ_BLOCK) {
+            const int f = k / 3, c = k % 3;
+            const int vi = F[3 * (f0 + f) + c];
+            s_idx[f][c] = vi;
+            s_tri[f][3 * c + 0] = V[3 * vi]; s_tri[f][3 * c + 1] = V[3 * vi + 1]; s_tri[f][3 * c + 2] = V[3 * vi + 2];
+        }
+        __syncthreads();
+        for (int f = 0; f < m; ++f) {
+            const f3 a = {s_tri[f][0], s_tri[f][1], s_tri[f][2]}, b = {s_tri[f][3], s_tri[f][4], s_tri[f][5]},
+                     c = {s_tri[f][6], s_tri[f][7], s_tri[f][8]};
+            const float d = point_tri_dist2(p, a, b, c);
+            if (d < best) { best = d; bf = f0 + f; }
+            // +x ray parity (oracle/mesh_oracle.c:point_inside)
+            const int i0 = s_idx[f][0], i1 = s_idx[f][1], i2 = s_idx[f][2];
+            float E0, E1, E2;
+            const bool s0 = edge_side(b, c, i1, i2, p.y, p.z, E0);
+            const bool s1 = edge_side(c, a, i2, i0, p.y, p.z, E1);
+            const bool s2 = edge_side(a, b, i0, i1, p.y, p.z, E2);
+            if ((s0 && s1 && s2) || (!s0 && !s1 && !s2)) {
+                const float den = (E0 + E1) + E2;
+                if (den != 0.0f) {
+                    const float xh = ((E0 * a.x + E1 * b.x) + E2 * c.x) / den;
+                    if (xh > p.x) ++cnt;
+                }
+            }
+        }
+    }
+    if (!live) return;
+    const float dist = sqrtf(best + 1e-6f);
+    sdf[i] = (cnt & 1) ? -dist : dist;
+    if (face) face[i] = bf;
+    // barycentric_coordinates_of_projection (mesh_util.py:321-356) on the closest face
+    const int i0 = F[3 * bf], i1 = F[3 * bf + 1], i2 = F[3 * bf + 2];
+    const f3 v0 = {V[3 * i0], V[3 * i0 + 1], V[3 * i0 + 2]}, v1 = {V[3 * i1], V[3 * i1 + 1], V[3 * i1 + 2]},
+             v2 = {V[3 * i2], V[3 * i2 + 1], V[3 * i2 + 2]};
+    const f3 u = sub3(v1, v0), v = sub3(v2, v0);
+    const f3 nrm = {u.y * v.z - u.z * v.y, u.z * v.x - u.x * v.z, u.x * v.y - u.y * v.x};
+    float s = dot3(nrm, nrm);
+    if (s == 0.0f) s = 1e-6f;
+    const float inv = 1.0f / s;
+    const f3 wv = sub3(p, v0);
+    const f3 c1 = {u.y * wv.z - u.z * wv.y, u.z * wv.x - u.x * wv.z, u.x * wv.y - u.y * wv.x};
+    const f3 c2 = {wv.y * v.z - wv.z * v.y, wv.z * v.x - wv.x * v.z, wv.x * v.y - wv.y * v.x};
+    const float b2 = dot3(c1, nrm) * inv;
+    const float b1 = dot3(c2, nrm) * inv;
+    const float w0 = (1.0f - b1) - b2;
+    const float sv = (w0 * vert_vis[i0] + b1 * vert_vis[i1]) + b2 * vert_vis[i2];
+    vis[i] = sv >= 0.1f;
+}
+
+// get_visibility: one thread per raster pixel, faces streamed through LDS
+constexpr int RV_BLOCK = 256;
+constexpr int RV_TILE = 256;
+
+__global__ __launch_bounds__(RV_BLOCK) void raster_kernel(const float* __restrict__ xy01, const float* __restrict__ z01,
+                                                          const int32_t* __restrict__ F, int nf, int S, int32_t* __restrict__ pix_to_face)
+{
+    __shared__ float s_v[RV_TILE][9];
+    const int pix = blockIdx.x * RV_BLOCK + threadIdx.x;
+    const bool live = pix < S * S;
+    const int px = pix % S, py = pix / S;
+    const float cx = -1.0f + (2.0f * (float)px + 1.0f) / (float)S;
+    const float cy = -1.0f + (2.0f * (float)py + 1.0f) / (float)S;
+    float bestz = INFINITY;
+    int bf = -1;
+    for (int f0 = 0; f0 < nf; f0 += RV_TILE) {
+        const int m = min(RV_TILE, nf - f0);
+        __syncthreads();
+        for (int k = threadIdx.x; k < m * 3; k += RV_BLOCK) {
+            const int f = k / 3, c = k % 3;
+            const int vi = F[3 * (f0 + f) + c];
+            s_v[f][3 * c + 0] = (xy01[2 * vi] + 1.0f) / 2.0f;
+            s_v[f][3 * c + 1] = (xy01[2 * vi + 1] + 1.0f) / 2.0f;
+            s_v[f][3 * c + 2] = (z01[vi] + 1.0f) / 2.0f;
+        }
+        __syncthreads();
+        for (int f = 0; f < m; ++f) {
+            const float* v0 = &s_v[f][0]; const float* v1 = &s_v[f][3]; const float* v2 = &s_v[f][6];
+            const float area = (v2[0] - v0[0]) * (v1[1] - v0[1]) - (v2[1] - v0[1]) * (v1[0] - v0[0]);
+            if (area < 0.0f) continue;
+            if (fabsf(area) <= 1e-8f) continue;
+            const float w0 = ((cx - v1[0]) * (v2[1] - v1[1]) - (cy - v1[1]) * (v2[0] - v1[0])) / area;
+            const float w1 = ((cx - v2[0]) * (v0[1] - v2[1]) - (cy - v2[1]) * (v0[0] - v2[0])) / area;
+            const float w2 = ((cx - v0[0]) * (v1[1] - v0[1]) - (cy - v0[1]) * (v1[0] - v0[0])) / area;
+            const float t0 = w0 * (v1[2] * v2[2]), t1 = w1 * (v0[2] * v2[2]), t2 = w2 * (v0[2] * v1[2]);
+            const float den = (t0 + t1) + t2;
+            if (den == 0.0f) continue;
+            const float b0 = t0 / den, b1 = t1 / den, b2 = t2 / den;
+            const float pz = (b0 * v0[2] + b1 * v1[2]) + b2 * v2[2];
+            if (pz < 0.0f) continue;
+            if (!(b0 > 0.0f && b1 > 0.0f && b2 > 0.0f)) continue;
+            if (pz < bestz) { bestz = pz; bf = f0 + f; }
+        }
+    }
+    if (live) pix_to_face[pix] = bf;
+}
+
+__global__ void mark_visible_kernel(const int32_t* __restrict__ pix_to_face, int npix, const int32_t* __restrict__ F, int nf,
+                                    float* __restrict__ vert_vis)
+{
+    const int pix = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pix >= npix) return;
+    int f = pix_to_face[pix];
+    if (f < 0) f = nf - 1; // faces[-1] through the background id (mesh_util.py:314)
+    vert_vis[F[3 * f]] = 1.0f; vert_vis[F[3 * f + 1]] = 1.0f; vert_vis[F[3 * f + 2]] = 1.0f;
+}
+
+__global__ __launch_bounds__(256) void knn1_kernel(const float4* __restrict__ verts, int nv, const float* __restrict__ pts, long long n,
+                                                   int32_t* __restrict__ idx)
+{
+    extern __shared__ float4 s_vv[];
+    for (int i = threadIdx.x; i < nv; i += blockDim.x) s_vv[i] = verts[i];
+    __syncthreads();
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float qx = pts[3 * i], qy = pts[3 * i + 1], qz = pts[3 * i + 2];
+    float best = INFINITY;
+    int bi = 0;
+    for (int j = 0; j < nv; ++j) {
+        const float4 v = s_vv[j];
+        const float dx = qx - v.x, dy = qy - v.y, dz = qz - v.z;
+        const float d = (dx * dx + dy * dy) + dz * dz;
+        if (d < best) { best = d; bi = j; }
+    }
+    idx[i] = bi;
+}
+
+} // namespace
+
+extern "C" int vanerf_vertex_visibility(const float* vert_xy01, const float* vert_z01, int nv, const int32_t* faces, int nf,
+                                        int raster, int32_t* pix_to_face, float* vert_vis, void* stream)
+{
+    return guarded([&] {
+        if (!vert_xy01 || !vert_z01 || !faces || !pix_to_face || !vert_vis) throw_error("vanerf_vertex_visibility: null argument");
+        if (nv <= 0 || nf <= 0 || raster <= 0 || raster > 4096) throw_error("vanerf_vertex_visibility: nv=%d nf=%d raster=%d", nv, nf, raster);
+        hipStream_t st = (hipStream_t)stream;
+        const int npix = raster * raster;
+        HIP_CHECK(hipMemsetAsync(vert_vis, 0, sizeof(float) * nv, st));
+        hipLaunchKernelGGL(raster_kernel, dim3((npix + RV_BLOCK - 1) / RV_BLOCK), dim3(RV_BLOCK), 0, st, vert_xy01, vert_z01, faces, nf, raster, pix_to_face);
+        hipLaunchKernelGGL(mark_visible_kernel, dim3((npix + 255) / 256), dim3(256), 0, st, pix_to_face, npix, faces, nf, vert_vis);
+        HIP_CHECK(hipGetLastError());
+    });
+}
+
+extern "C" int vanerf_mesh_query(const float* verts, int nv, const int32_t* faces, int nf, const float* vert_vis, const float* pts,
+                                 int64_t n, float* sdf, uint8_t* vis, int32_t* face, void* stream)
+{
+    return guarded([&] {
+        if (!verts || !faces || !vert_vis || !pts || !sdf || !vis) throw_error("vanerf_mesh_query: null argument");
+        if (nv <= 0 || nf <= 0 || n < 0) throw_error("vanerf_mesh_query: nv=%d nf=%d n=%lld", nv, nf, (long long)n);
+        if (n == 0) return;
+        hipLaunchKernelGGL(mesh_query_kernel, dim3((unsigned)((n + MQ_BLOCK - 1) / MQ_BLOCK)), dim3(MQ_BLOCK), 0, (hipStream_t)stream,
+                           verts, faces, nf, vert_vis, pts, (long long)n, sdf, vis, face);
+        HIP_CHECK(hipGetLastError());
+    });
+}
+
+extern "C" int vanerf_knn1(const float* verts4, int nv, const float* pts, int64_t n, int32_t* idx, void* stream)
+{
+    return guarded([&] {
+        if (!verts4 || !pts || !idx) throw_error("vanerf_knn1: null argument");
+        if (nv <= 0 || nv > 8192 || n < 0) throw_error("vanerf_knn1: nv=%d n=%lld", nv, (long long)n);
+        if (n == 0) return;
+        hipLaunchKernelGGL(knn1_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), sizeof(float4) * nv, (hipStream_t)stream,
+                           reinterpret_cast<const float4*>(verts4), nv, pts, (long long)n, idx);
+        HIP_CHECK(hipGetLastError());
+    });
+}

@@ -1,0 +1,308 @@
+// render_kernels.hip -- the per-ray ends of the march: pixel grid + ray generation + bbox clipping +
+// coarse depths (src/model.py:1191-1238, 1496-1570), sample positions (1234-1235), alpha compositing
+// (879-882, 1464-1494) and inverse-CDF importance sampling + sort-merge (1424-1462, 1301-1307).
+// All of it is HBM-bound streaming work: one thread per ray, rows of S floats.
+// Built with -ffp-contract=off (mul and add stay separate IEEE operations, as in eager PyTorch).
+#include <algorithm>
+
+#include "common.h"
+
+using namespace vanerf;
+
+namespace {
+
+struct RayParams {
+    int x0, y0, step, nx, ny, width;
+    float invK_T[9];
+    float RT[12];
+    float znear, zfar;
+    float bounds[6];
+    int S;
+    const float* t_lin;
+    const float* jitter;
+    int64_t* index;
+    float* rays_d;
+    float* cam_pos;
+    float* near;
+    float* far;
+    uint8_t* hit;
+    float* z;
+};
+
+__device__ __forceinline__ float norm3(float a, float b, float c) { return sqrtf((a * a + b * b) + c * c); }
+
+__global__ void ray_setup_kernel(const RayParams P)
+{
+    const int R = P.nx * P.ny;
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    // camera centre: -(t . R)  (src/model.py:1213)
+    const float* M = P.RT;
+    const float tx = M[3], ty = M[7], tz = M[11];
+    const float ox = -((tx * M[0] + ty * M[4]) + tz * M[8]);
+    const float oy = -((tx * M[1] + ty * M[5]) + tz * M[9]);
+    const float oz = -((tx * M[2] + ty * M[6]) + tz * M[10]);
+    if (r == 0) { P.cam_pos[0] = ox; P.cam_pos[1] = oy; P.cam_pos[2] = oz; }
+    if (r >= R) return;
+    const int ix = r % P.nx, iy = r / P.nx;
+    const int gxi = P.x0 + ix * P.step, gyi = P.y0 + iy * P.step;
+    P.index[r] = (int64_t)gxi + (int64_t)gyi * P.width;
+    const float gx = (float)gxi, gy = (float)gyi;
+    const float* K = P.invK_T; // row-major 3x3: c_j = gx*K[0][j] + gy*K[1][j] + K[2][j]
+    float c0 = (gx * K[0] + gy * K[3]) + K[6];
+    float c1 = (gx * K[1] + gy * K[4]) + K[7];
+    float c2 = (gx * K[2] + gy * K[5]) + K[8];
+    // znear/zfar along the ray: || (z * [x, y, 1]) K^-T ||  (src/model.py:1204-1211)
+    float nx_ = P.znear * gx, ny_ = P.znear * gy, nz_ = P.znear;
+    float zn = norm3((nx_ * K[0] + ny_ * K[3]) + nz_ * K[6], (nx_ * K[1] + ny_ * K[4]) + nz_ * K[7], (nx_ * K[2] + ny_ * K[5]) + nz_ * K[8]);
+    float fx_ = P.zfar * gx, fy_ = P.zfar * gy, fz_ = P.zfar;
+    float zf = norm3((fx_ * K[0] + fy_ * K[3]) + fz_ * K[6], (fx_ * K[1] + fy_ * K[4]) + fz_ * K[7], (fx_ * K[2] + fy_ * K[5]) + fz_ * K[8]);
+    // world direction: normalize(c . R)
+    float dx = (c0 * M[0] + c1 * M[4]) + c2 * M[8];
+    float dy = (c0 * M[1] + c1 * M[5]) + c2 * M[9];
+    float dz = (c0 * M[2] + c1 * M[6]) + c2 * M[10];
+    float nrm = fmaxf(norm3(dx, dy, dz), 1e-12f);
+    dx /= nrm; dy /= nrm; dz /= nrm;
+    P.rays_d[3 * r] = dx; P.rays_d[3 * r + 1] = dy; P.rays_d[3 * r + 2] = dz;
+
+    // ray_bbox_intersection (src/model.py:1496-1570)
+    const float lo[3] = {P.bounds[0] - 0.01f, P.bounds[1] - 0.01f, P.bounds[2] - 0.01f};
+    const float hi[3] = {P.bounds[3] + 0.01f, P.bounds[4] + 0.01f, P.bounds[5] + 0.01f};
+    float d[3] = {dx, dy, dz};
+    const float o[3] = {ox, oy, oz};
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+        if (fabsf(d[a]) < 1e-5f) d[a] = 1e-5f;
+    const float eps = 1e-6f;
+    int cnt = 0;
+    float dist[2] = {0.0f, 0.0f};
+    const float nd = norm3(d[0], d[1], d[2]);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { // order: min_x, min_y, min_z, max_x, max_y, max_z
+        const int a = k % 3;
+        const float plane = k < 3 ? lo[a] : hi[a];
+        const float t = (plane - o[a]) / d[a];
+        const float p0 = t * d[0] + o[0], p1 = t * d[1] + o[1], p2 = t * d[2] + o[2];
+        const bool in = (p0 >= lo[0] - eps) && (p0 <= hi[0] + eps) && (p1 >= lo[1] - eps) && (p1 <= hi[1] + eps) &&
+                        (p2 >= lo[2] - eps) && (p2 <= hi[2] + eps);
+        if (in) {
+            if (cnt < 2) dist[cnt] = norm3(p0 - o[0], p1 - o[1], p2 - o[2]) / nd;
+            ++cnt;
+        }
+    }
+    const bool hit = cnt == 2;
+    const float z1 = hit ? fminf(dist[0], dist[1]) : 1.0f;
+    const float z2 = hit ? fmaxf(dist[0], dist[1]) : 1.0f;
+    const float near = (hit && z1 > zn) ? z1 : zn; // src/model.py:1217-1220
+    const float far = (hit && z2 < zf) ? z2 : zf;
+    P.near[r] = near; P.far[r] = far; P.hit[r] = hit;
+
+    // coarse depths (src/model.py:1222-1232)
+    const int S = P.S;
+    for (int i = 0; i < S; ++i) {
+        float t = P.t_lin[i];
+        if (P.jitter) {
+            float lo_t = i == 0 ? P.t_lin[0] : 0.5f * (P.t_lin[i] + P.t_lin[i - 1]);
+            float hi_t = i == S - 1 ? P.t_lin[S - 1] : 0.5f * (P.t_lin[i + 1] + P.t_lin[i]);
+            t = lo_t + P.jitter[(size_t)r * S + i] * (hi_t - lo_t);
+        }
+        P.z[(size_t)r * S + i] = near + (far - near) * t;
+    }
+}
+
+__global__ void sample_points_kernel(const float* __restrict__ rays_d, const float* __restrict__ cam_pos,
+                                     const float* __restrict__ z, long long n, int S, float* __restrict__ pts)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const long long r = i / S;
+    const float t = z[i];
+    pts[3 * i + 0] = cam_pos[0] + rays_d[3 * r + 0] * t;
+    pts[3 * i + 1] = cam_pos[1] + rays_d[3 * r + 1] * t;
+    pts[3 * i + 2] = cam_pos[2] + rays_d[3 * r + 2] * t;
+}
+
+// sdf_activation + rgba2out.  Sums are accumulated in fp64 from fp32 products so the result does not
+// depend on the summation order (the reference's float .sum() order is an implementation detail).
+__global__ void composite_kernel(const float* __restrict__ rgba, const float* __restrict__ z, const float* __restrict__ msdf,
+                                 int R, int S, float beta, float* __restrict__ color, float* __restrict__ depth,
+                                 float* __restrict__ alpha, float* __restrict__ sdf, float* __restrict__ contrib)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    const float* q = rgba + (size_t)r * S * 5;
+    const float* zr = z + (size_t)r * S;
+    const float* ms = msdf + (size_t)r * S;
+    double cr = 0, cg = 0, cb = 0, ca = 0, cs = 0, cd = 0;
+    float T = 1.0f;
+    float zi = zr[0];
+    for (int i = 0; i < S; ++i) {
+        const float zn = i + 1 < S ? zr[i + 1] : 0.0f;
+        const float dist = i + 1 < S ? zn - zi : 1e10f;
+        const float a = q[5 * i] + ms[i];
+        const float sg = (1.0f / (1.0f + expf(-(-a / beta)))) / beta; // sigmoid(-a / beta) / beta
+        const float c = 1.0f - expf(-sg * dist);
+        const float w = c * T;
+        T = T * (1.0f - c);
+        if (contrib) contrib[(size_t)r * S + i] = w;
+        cr += (double)(q[5 * i + 2] * w);
+        cg += (double)(q[5 * i + 3] * w);
+        cb += (double)(q[5 * i + 4] * w);
+        ca += (double)w;
+        cs += (double)(q[5 * i + 1] * w);
+        cd += (double)(zi * w);
+        zi = zn;
+    }
+    const float acc = (float)ca;
+    color[3 * r] = (float)cr; color[3 * r + 1] = (float)cg; color[3 * r + 2] = (float)cb;
+    alpha[r] = acc;
+    sdf[r] = (float)cs / (acc + 1e-8f);
+    depth[r] = (float)cd / (acc + 1e-8f);
+}
+
+// importance_sample + sort-merge, one thread per ray; per-thread arrays live in LDS with a 64-thread stride
+// (element i of thread t at [i*64 + t]: conflict-free).
+constexpr int IM_BLOCK = 64;
+
+__global__ __launch_bounds__(IM_BLOCK) void importance_merge_kernel(const float* __restrict__ contrib, const float* __restrict__ z,
+                                                                    const float* __restrict__ u, const float* __restrict__ t_lin, int R,
+                                                                    int Sc, int Sf, float* __restrict__ z_new, float* __restrict__ z_fine,
+                                                                    int32_t* __restrict__ src, int32_t* __restrict__ idx_out)
+{
+    extern __shared__ float lds[];
+    const int t = threadIdx.x;
+    const int r = blockIdx.x * IM_BLOCK + t;
+    const int nb = Sc - 2; // bins
+    float* cdf = lds + t;                          // nb + 1 entries
+    float* zmid = cdf + (size_t)(nb + 1) * IM_BLOCK; // nb + 1 entries
+    float* smp = zmid + (size_t)(nb + 1) * IM_BLOCK; // Sf entries
+    if (r >= R) return;
+    const float* c = contrib + (size_t)r * Sc;
+    const float* zr = z + (size_t)r * Sc;
+    // pdf = (contrib[1:-1] + 1e-5) / sum ; cdf = [0, cumsum(pdf)] (fp64 accumulate, fp32 values)
+    double tot = 0.0;
+    for (int i = 0; i < nb; ++i) tot += (double)(c[i + 1] + 1e-5f);
+    const float sum = (float)tot;
+    double run = 0.0;
+    cdf[0] = 0.0f;
+    for (int i = 0; i < nb; ++i) {
+        run += (double)((c[i + 1] + 1e-5f) / sum);
+        cdf[(size_t)(i + 1) * IM_BLOCK] = (float)run;
+    }
+    for (int i = 0; i < nb + 1; ++i) zmid[(size_t)i * IM_BLOCK] = 0.5f * (zr[i + 1] + zr[i]);
+    bool sorted = true;
+    float prev = -INFINITY;
+    for (int k = 0; k < Sf; ++k) {
+        const float uk = u ? u[(size_t)r * Sf + k] : t_lin[k];
+        // searchsorted(cdf, uk, right=True): first position with cdf > uk
+        int lo = 0, hi = nb + 1;
+        while (lo < hi) {
+            int mid = (lo + hi) >> 1;
+            if (cdf[(size_t)mid * IM_BLOCK] <= uk) lo = mid + 1; else hi = mid;
+        }
+        const int ip = max(lo - 1, 0), in = min(lo, nb);
+        const float cp = cdf[(size_t)ip * IM_BLOCK], cn = cdf[(size_t)in * IM_BLOCK];
+        const float zp = zmid[(size_t)ip * IM_BLOCK], zq = zmid[(size_t)in * IM_BLOCK];
+        float den = cn - cp;
+        if (den < 1e-5f) den = 1.0f;
+        const float s = zp + ((uk - cp) / den) * (zq - zp);
+        smp[(size_t)k * IM_BLOCK] = s;
+        z_new[(size_t)r * Sf + k] = s;
+        if (idx_out) idx_out[(size_t)r * Sf + k] = in;
+        sorted = sorted && (s >= prev);
+        prev = s;
+    }
+    // sort-merge (th.sort(th.cat([z, z_fine]))): stable merge of the two runs; the new samples are sorted first if
+    // needed (random u in training, or a last-bit inversion), remembering where each merged sample came from.
+    int32_t* srow = src + (size_t)r * (Sc + Sf);
+    float* frow = z_fine + (size_t)r * (Sc + Sf);
+    int* perm = reinterpret_cast<int*>(smp + (size_t)Sf * IM_BLOCK); // Sf entries
+    for (int k = 0; k < Sf; ++k) perm[(size_t)k * IM_BLOCK] = k;
+    if (!sorted) { // insertion sort (values + origin)
+        for (int k = 1; k < Sf; ++k) {
+            const float v = smp[(size_t)k * IM_BLOCK];
+            const int pv = perm[(size_t)k * IM_BLOCK];
+            int m = k - 1;
+            while (m >= 0 && smp[(size_t)m * IM_BLOCK] > v) {
+                smp[(size_t)(m + 1) * IM_BLOCK] = smp[(size_t)m * IM_BLOCK];
+                perm[(size_t)(m + 1) * IM_BLOCK] = perm[(size_t)m * IM_BLOCK];
+                --m;
+            }
+            smp[(size_t)(m + 1) * IM_BLOCK] = v;
+            perm[(size_t)(m + 1) * IM_BLOCK] = pv;
+        }
+    }
+    int a = 0, b = 0;
+    for (int k = 0; k < Sc + Sf; ++k) {
+        const float za = a < Sc ? zr[a] : INFINITY;
+        const float zb = b < Sf ? smp[(size_t)b * IM_BLOCK] : INFINITY;
+        const bool take_a = (a < Sc) && (b >= Sf || za <= zb);
+        if (take_a) { frow[k] = za; srow[k] = a; ++a; }
+        else { frow[k] = zb; srow[k] = ~perm[(size_t)b * IM_BLOCK]; ++b; }
+    }
+}
+
+} // namespace
+
+extern "C" int vanerf_ray_setup(int x0, int y0, int step, int nx, int ny, int width, const float* invK_T, const float* RT,
+                                float znear, float zfar, const float* bounds, int S, const float* t_lin, const float* jitter,
+                                int64_t* index, float* rays_d, float* cam_pos, float* near, float* far, uint8_t* hit, float* z,
+                                void* stream)
+{
+    return guarded([&] {
+        if (!invK_T || !RT || !bounds || !t_lin || !index || !rays_d || !cam_pos || !near || !far || !hit || !z)
+            throw_error("vanerf_ray_setup: null argument");
+        if (nx <= 0 || ny <= 0 || step <= 0 || S < 2 || width <= 0) throw_error("vanerf_ray_setup: bad grid (nx=%d ny=%d step=%d S=%d)", nx, ny, step, S);
+        RayParams P;
+        P.x0 = x0; P.y0 = y0; P.step = step; P.nx = nx; P.ny = ny; P.width = width;
+        std::copy_n(invK_T, 9, P.invK_T);
+        std::copy_n(RT, 12, P.RT);
+        std::copy_n(bounds, 6, P.bounds);
+        P.znear = znear; P.zfar = zfar; P.S = S; P.t_lin = t_lin; P.jitter = jitter;
+        P.index = index; P.rays_d = rays_d; P.cam_pos = cam_pos; P.near = near; P.far = far; P.hit = hit; P.z = z;
+        const int R = nx * ny;
+        hipLaunchKernelGGL(ray_setup_kernel, dim3((R + 255) / 256), dim3(256), 0, (hipStream_t)stream, P);
+        HIP_CHECK(hipGetLastError());
+    });
+}
+
+extern "C" int vanerf_sample_points(const float* rays_d, const float* cam_pos, const float* z, int R, int S, float* pts, void* stream)
+{
+    return guarded([&] {
+        if (!rays_d || !cam_pos || !z || !pts) throw_error("vanerf_sample_points: null argument");
+        if (R <= 0 || S <= 0) throw_error("vanerf_sample_points: R=%d S=%d", R, S);
+        const long long n = (long long)R * S;
+        hipLaunchKernelGGL(sample_points_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rays_d, cam_pos, z, n, S, pts);
+        HIP_CHECK(hipGetLastError());
+    });
+}
+
+extern "C" int vanerf_composite(const float* rgba, const float* z, const float* mesh_sdf, int R, int S, float beta,
+                                float* color, float* depth, float* alpha, float* sdf, float* contrib, void* stream)
+{
+    return guarded([&] {
+        if (!rgba || !z || !mesh_sdf || !color || !depth || !alpha || !sdf) throw_error("vanerf_composite: null argument");
+        if (R <= 0 || S <= 0) throw_error("vanerf_composite: R=%d S=%d", R, S);
+        if (!(beta > 0.0f)) throw_error("vanerf_composite: beta must be positive");
+        if (beta < 2e-3f) beta = 2e-3f; // sdf_activation clamp (src/model.py:880)
+        hipLaunchKernelGGL(composite_kernel, dim3((R + 63) / 64), dim3(64), 0, (hipStream_t)stream, rgba, z, mesh_sdf, R, S, beta,
+                           color, depth, alpha, sdf, contrib);
+        HIP_CHECK(hipGetLastError());
+    });
+}
+
+extern "C" int vanerf_importance_merge(const float* contrib, const float* z, const float* u, const float* t_lin, int R, int Sc, int Sf,
+                                       float* z_new, float* z_fine, int32_t* src, int32_t* idx, void* stream)
+{
+    return guarded([&] {
+        if (!contrib || !z || !z_new || !z_fine || !src) throw_error("vanerf_importance_merge: null argument");
+        if (!u && !t_lin) throw_error("vanerf_importance_merge: need u (random) or t_lin (uniform)");
+        if (R <= 0 || Sc < 3 || Sf < 1) throw_error("vanerf_importance_merge: R=%d Sc=%d Sf=%d", R, Sc, Sf);
+        const size_t lds = (size_t)IM_BLOCK * sizeof(float) * (2 * (size_t)(Sc - 1) + 2 * (size_t)Sf);
+        if (lds > 160 * 1024) throw_error("vanerf_importance_merge: %d + %d samples per ray exceed LDS", Sc, Sf);
+        if (lds > 64 * 1024)
+            HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(importance_merge_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(importance_merge_kernel, dim3((R + IM_BLOCK - 1) / IM_BLOCK), dim3(IM_BLOCK), lds, (hipStream_t)stream,
+                           contrib, z, u, t_lin, R, Sc, Sf, z_new, z_fine, src, idx);
+        HIP_CHECK(hipGetLastError());
+    });
+}

@@ -1,0 +1,353 @@
+"""Host side of the MI355X render path: torch tensors in, C-ABI calls into libvanerf_hip.so, torch tensors out.
+
+PyTorch is used here for device memory, streams and the per-frame (not per-sample) preparation
+that the north-star keeps on PyTorch-ROCm (feature un-projection at the mesh vertices, the
+TexVisFusion per-frame conv stack).  Every per-ray / per-sample operation runs in the HIP library.
+There is no CPU or eager fallback: every entry point requires CUDA(ROCm) tensors.
+"""
+import ctypes
+import math
+from ctypes import POINTER, byref, c_float, c_int64, c_uint, c_void_p
+
+import torch
+import torch.nn.functional as F
+
+from . import _ffi
+from ._ffi import VanerfFrame, VanerfWeightTable, check, lib
+
+NV, NV_HAND, NKPT = 1558, 779, 42
+
+
+def _ptr(t, dtype=None, cuda=True):
+    if t is None:
+        return None
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError(f"expected {dtype}, got {t.dtype}")
+    if cuda and not t.is_cuda:
+        raise ValueError("the HIP render path needs device tensors (no CPU fallback)")
+    if not t.is_contiguous():
+        raise ValueError("tensor must be contiguous")
+    return c_void_p(t.data_ptr())
+
+
+def _stream():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _farr(values, n):
+    vals = [float(v) for v in values]
+    assert len(vals) == n, (len(vals), n)
+    return (c_float * n)(*vals)
+
+
+# ------------------------------------------------------------------------------------------------
+# weights
+# ------------------------------------------------------------------------------------------------
+_CONV_KEYS = {
+    "geo_at0_w1": "geo_vis_fusion.fconv_at.0.weight", "geo_at0_w2": "geo_vis_fusion.fconv_at.2.weight",
+    "geo_ated0_w1": "geo_vis_fusion.fconv_ated.0.weight", "geo_ated0_w2": "geo_vis_fusion.fconv_ated.2.weight",
+    "geo_at1_w1": "geo_vis_fusion.fconv_at1.0.weight", "geo_at1_w2": "geo_vis_fusion.fconv_at1.2.weight",
+    "geo_ated1_w1": "geo_vis_fusion.fconv_ated1.0.weight", "geo_ated1_w2": "geo_vis_fusion.fconv_ated1.2.weight",
+    "tex_at_w1": "tex_vis_fusion.fconv_at.0.weight", "tex_at_w2": "tex_vis_fusion.fconv_at.2.weight",
+    "tex_w1": "tex_vis_fusion.fconv.0.weight", "tex_w2": "tex_vis_fusion.fconv.2.weight",
+    "l1_w3": "mlp_geo.layers1.layers.3.linear.weight", "l1_b3": "mlp_geo.layers1.layers.3.linear.bias",
+    "l2_w2": "mlp_geo.layers2.layers.2.linear.weight", "l2_b2": "mlp_geo.layers2.layers.2.linear.bias",
+    "ibr_w": "ibr_compress_gfeat.weight", "ibr_b": "ibr_compress_gfeat.bias",
+}
+_EXPECT = {
+    "geo_at0_w1": (10, 196), "geo_at0_w2": (3, 10), "geo_ated0_w1": (64, 196), "geo_ated0_w2": (64, 64),
+    "geo_at1_w1": (10, 28), "geo_at1_w2": (3, 10), "geo_ated1_w1": (8, 28), "geo_ated1_w2": (8, 8),
+    "tex_at_w1": (96, 96), "tex_at_w2": (6, 96), "tex_w1": (96, 96), "tex_w2": (40, 96),
+    "l1_w3": (64, 120), "l1_b3": (64,), "l2_w2": (2, 64), "l2_b2": (2,), "ibr_w": (24, 128), "ibr_b": (24,),
+}
+_L1 = [(128, 358), (128, 128), (120, 136)]
+_L2 = [(64, 128), (64, 64)]
+
+
+def weight_table(sd):
+    """Reference state_dict (key names of VANeRF.state_dict()) -> (VanerfWeightTable, keep-alive list of host tensors)."""
+    keep = []
+
+    def host(key, shape):
+        t = sd[key].detach().to("cpu", torch.float32)
+        if t.dim() == 3 and t.shape[-1] == 1:
+            t = t[:, :, 0]
+        t = t.reshape(shape).contiguous()
+        keep.append(t)
+        return c_void_p(t.data_ptr())
+
+    tab = VanerfWeightTable()
+    for field, key in _CONV_KEYS.items():
+        setattr(tab, field, host(key, _EXPECT[field]))
+    for i, (o, k) in enumerate(_L1):
+        p = f"mlp_geo.layers1.layers.{i}.linear."
+        tab.l1_v[i], tab.l1_g[i], tab.l1_b[i] = host(p + "weight_v", (o, k)), host(p + "weight_g", (o,)), host(p + "bias", (o,))
+    for i, (o, k) in enumerate(_L2):
+        p = f"mlp_geo.layers2.layers.{i}.linear."
+        tab.l2_v[i], tab.l2_g[i], tab.l2_b[i] = host(p + "weight_v", (o, k)), host(p + "weight_g", (o,)), host(p + "bias", (o,))
+    tab.sigmoid_beta = float(sd["sigmoid_beta"].detach().reshape(-1)[0])
+    return tab, keep
+
+
+class PackedWeights:
+    """Device-resident MFMA-fragment copy of the per-sample network weights (vanerf_weights_pack)."""
+
+    def __init__(self, sd, mode=0):
+        tab, keep = weight_table(sd)
+        h = c_void_p()
+        check(lib.vanerf_weights_pack(byref(tab), mode, byref(h)))
+        self.handle = h
+        self.beta = max(float(tab.sigmoid_beta), 2e-3)  # sdf_activation clamp (src/model.py:880)
+
+    def close(self):
+        if getattr(self, "handle", None):
+            lib.vanerf_weights_free(self.handle)
+            self.handle = None
+
+    __del__ = close
+
+
+def pack_weights_host(sd):
+    """CPU-only view of the packed stream (tests of the packer): (float32 tensor, offsets list)."""
+    tab, keep = weight_table(sd)
+    n = c_int64()
+    offs = (c_uint * _ffi.NUM_LAYERS)()
+    check(lib.vanerf_weights_pack_host(byref(tab), None, 0, byref(n), offs))
+    out = torch.empty(n.value, dtype=torch.float32)
+    check(lib.vanerf_weights_pack_host(byref(tab), c_void_p(out.data_ptr()), n.value, byref(n), offs))
+    return out, list(offs)
+
+
+# ------------------------------------------------------------------------------------------------
+# per-frame preparation (torch on the device; src/model.py:845-853, src/networks.py:83, 96, 270-279)
+# ------------------------------------------------------------------------------------------------
+def _grid_sample(feat, uv):
+    out = F.grid_sample(feat, uv[:, :, None], mode="bilinear", padding_mode="border", align_corners=True)
+    return out.view(*out.shape[:2], -1).permute(0, 2, 1)
+
+
+def _project(pts, KRT):
+    vh = pts @ KRT[:, :3, :3].transpose(1, 2) + KRT[:, :3, 3][:, None]
+    return vh[..., :2], vh[..., 2:3]
+
+
+def tex_global_vertex_feature(sd, feat_tex, img, pre="tex_vis_fusion."):
+    """TexVisFusion's per-frame global feature (src/networks.py:273-278): (B,1558,18)."""
+    def stack(x, name, hw):
+        x = F.conv2d(x, sd[pre + name + ".0.weight"], padding=1)
+        x = torch.relu(F.layer_norm(x, [hw, hw], sd[pre + name + ".1.weight"], sd[pre + name + ".1.bias"], 1e-6))
+        x = F.conv2d(x, sd[pre + name + ".3.weight"], padding=1)
+        x = torch.relu(F.layer_norm(x, [hw, hw], sd[pre + name + ".4.weight"], sd[pre + name + ".4.bias"], 1e-6))
+        return F.adaptive_avg_pool2d(x, 3)
+
+    gf = stack(feat_tex, "fconv3", feat_tex.shape[-1]).reshape(feat_tex.shape[0], 42, -1)
+    gf_img = stack(img, "fconv4", img.shape[-1]).reshape(img.shape[0], 42, -1)
+    gf = torch.cat([gf_img, gf], -1)
+    x = F.conv1d(gf, sd[pre + "fconv_gt.0.weight"], padding=1)
+    x = torch.relu(F.layer_norm(x, [18], sd[pre + "fconv_gt.1.weight"], sd[pre + "fconv_gt.1.bias"], 1e-6))
+    x = F.conv1d(x, sd[pre + "fconv_gt.3.weight"], padding=1)
+    return torch.relu(F.layer_norm(x, [18], sd[pre + "fconv_gt.4.weight"], sd[pre + "fconv_gt.4.bias"], 1e-6))
+
+
+class FrameData:
+    """Everything the per-sample kernel needs about one source frame, resident in HBM (struct VanerfFrame)."""
+
+    def __init__(self, sd, img, feat_geo, feat_tex, fg_mask, cam_in, targets, sp_data, sp_args=None, gf=None):
+        sp_args = sp_args or {"scale": 1.0, "sigma": 0.1}
+        dev = img.device
+        if not img.is_cuda:
+            raise ValueError("FrameData needs device tensors (no CPU fallback)")
+        if img.shape[0] != 1 or cam_in["KRT"].shape[0] != 1:
+            raise AssertionError("n_views == 1 and batch == 1 (src/networks.py:86,94 is single-view)")
+        f32 = torch.float32
+        KRT = cam_in["KRT"].to(dev, f32)
+        verts = targets["vert_world"].to(dev, f32)
+        faces = targets["face_world"].to(dev).long()
+        assert verts.shape == (1, NV, 3), verts.shape
+        W, H = float(cam_in["width"]), float(cam_in["height"])
+        znear, zfar = float(cam_in["znear"]), float(cam_in["zfar"])
+        # vertices in the source view (src/model.py:845-853 for sampling, 1245-1255 for the visibility raster)
+        vxy, vz = _project(verts, KRT)
+        vxy = vxy / (vz + 1e-8)
+        vert_uv = torch.stack([2.0 * (vxy[..., 0] / (W - 1.0)) - 1.0, 2.0 * (vxy[..., 1] / (H - 1.0)) - 1.0], -1)
+        self.vert_xy01 = torch.stack([vxy[..., 0] / (W - 1.0), vxy[..., 1] / (H - 1.0)], -1)[0].contiguous()
+        self.vert_z01 = ((vz - znear) / (zfar - znear))[0, :, 0].contiguous()
+        self.faces = faces[0].to(torch.int32).contiguous()
+        self.verts3 = verts[0].contiguous()
+        self.vert_vis = vertex_visibility(self.vert_xy01, self.vert_z01, self.faces)
+        vis = self.vert_vis[None, :, None]
+        # per-vertex features, pre-multiplied by visibility (KNN_vis, src/networks.py:29-32)
+        img = img.to(f32)
+        self.vfeat0 = (_grid_sample(feat_geo[0], vert_uv) * vis)[0].contiguous()
+        self.vfeat1 = (_grid_sample(feat_geo[1], vert_uv) * vis)[0].contiguous()
+        if gf is None:
+            gf = tex_global_vertex_feature(sd, feat_tex, img)
+        vt = torch.cat([_grid_sample(img, vert_uv), _grid_sample(feat_tex, vert_uv), gf, torch.zeros(1, NV, 3, device=dev)], 2) * vis
+        self.vfeat_tex = vt[0].contiguous()
+        assert self.vfeat0.shape == (NV, 64) and self.vfeat1.shape == (NV, 8) and self.vfeat_tex.shape == (NV, 32)
+        # channel-last maps
+        self.geo0 = feat_geo[0][0].permute(1, 2, 0).contiguous()
+        self.geo1 = feat_geo[1][0].permute(1, 2, 0).contiguous()
+        self.tex = feat_tex[0].permute(1, 2, 0).contiguous()
+        self.img = torch.cat([img[0], torch.zeros_like(img[0, :1])], 0).permute(1, 2, 0).contiguous()
+        self.mask = fg_mask.reshape(fg_mask.shape[-2], fg_mask.shape[-1]).to(dev, f32).contiguous()
+        assert self.geo0.shape[-1] == 64 and self.geo1.shape[-1] == 8 and self.tex.shape[-1] == 8
+        assert self.mask.shape == self.img.shape[:2]
+        self.verts4 = torch.cat([verts[0], torch.zeros(NV, 1, device=dev)], 1).contiguous()
+        ext = sp_data["extrin"].to(dev, f32)
+        kpt = sp_data["kpt3d"].to(dev, f32)
+        assert kpt.shape == (1, NKPT, 3), kpt.shape
+        kc = kpt @ ext[:, :3, :3].transpose(1, 2) + ext[:, :3, 3][:, None]
+        self.kpt_cam = torch.cat([kc[0], torch.zeros(NKPT, 1, device=dev)], 1).contiguous()
+
+        c = VanerfFrame()
+        c.geo0, c.geo1, c.tex, c.img, c.mask = (_ptr(t, f32) for t in (self.geo0, self.geo1, self.tex, self.img, self.mask))
+        c.h0, c.w0 = self.geo0.shape[:2]
+        c.h1, c.w1 = self.geo1.shape[:2]
+        c.ht, c.wt = self.tex.shape[:2]
+        c.hi, c.wi = self.img.shape[:2]
+        c.verts, c.vfeat0, c.vfeat1, c.vfeat_tex = (_ptr(t, f32) for t in (self.verts4, self.vfeat0, self.vfeat1, self.vfeat_tex))
+        c.vert_vis, c.kpt_cam = _ptr(self.vert_vis, f32), _ptr(self.kpt_cam, f32)
+        c.KRT = _farr(KRT[0, :3, :4].reshape(-1).tolist(), 12)
+        c.extrin = _farr(ext[0, :3, :4].reshape(-1).tolist(), 12)
+        c.width, c.height, c.znear, c.zfar = W, H, znear, zfar
+        c.invalid_sdf = 0.1 / float(cam_in["nml_scale"])
+        c.pe_scale = float(sp_args.get("scale", 1.0))
+        c.pe_inv_2sigma2 = 1.0 / (2.0 * float(sp_args.get("sigma", 0.1)) ** 2)
+        self.c = c
+
+
+# ------------------------------------------------------------------------------------------------
+# thin wrappers over the C ABI (one per entry point)
+# ------------------------------------------------------------------------------------------------
+def vertex_visibility(vert_xy01, vert_z01, faces_i32, raster=256):
+    """get_visibility (mesh_util.py:284-318) -> (NV,) float {0,1}."""
+    nv = vert_xy01.shape[0]
+    vis = torch.empty(nv, dtype=torch.float32, device=vert_xy01.device)
+    scratch = torch.empty(raster * raster, dtype=torch.int32, device=vert_xy01.device)
+    check(lib.vanerf_vertex_visibility(_ptr(vert_xy01, torch.float32), _ptr(vert_z01, torch.float32), nv, _ptr(faces_i32, torch.int32),
+                                       faces_i32.shape[0], raster, _ptr(scratch), _ptr(vis), _stream()))
+    return vis
+
+
+def mesh_query(verts3, faces_i32, vert_vis, pts, want_face=False):
+    """cal_vis_sdf_batch (mesh_util.py:498-524) -> sdf (N,), vis (N,) uint8[, closest face (N,) int32]."""
+    n = pts.shape[0]
+    sdf = torch.empty(n, dtype=torch.float32, device=pts.device)
+    vis = torch.empty(n, dtype=torch.uint8, device=pts.device)
+    face = torch.empty(n, dtype=torch.int32, device=pts.device) if want_face else None
+    check(lib.vanerf_mesh_query(_ptr(verts3, torch.float32), verts3.shape[0], _ptr(faces_i32, torch.int32), faces_i32.shape[0],
+                                _ptr(vert_vis, torch.float32), _ptr(pts, torch.float32), n, _ptr(sdf), _ptr(vis), _ptr(face), _stream()))
+    return (sdf, vis, face) if want_face else (sdf, vis)
+
+
+def knn1(verts4, pts):
+    idx = torch.empty(pts.shape[0], dtype=torch.int32, device=pts.device)
+    check(lib.vanerf_knn1(_ptr(verts4, torch.float32), verts4.shape[0], _ptr(pts, torch.float32), pts.shape[0], _ptr(idx), _stream()))
+    return idx
+
+
+def query_samples(weights, frame, pts, query_sdf, query_vis, noise=None, want_valid=False, want_knn=False):
+    """VANeRF.query + eval_func (src/model.py:748-957, 1140-1160): (N,3),(N,),(N,)u8 -> (N,5) [alpha, sdf, r, g, b]."""
+    n = pts.shape[0]
+    out = torch.empty(n, 5, dtype=torch.float32, device=pts.device)
+    valid = torch.empty(n, dtype=torch.uint8, device=pts.device) if want_valid else None
+    knn = torch.empty(n, dtype=torch.int32, device=pts.device) if want_knn else None
+    check(lib.vanerf_query_samples(weights.handle, byref(frame.c), _ptr(pts, torch.float32), _ptr(query_sdf, torch.float32),
+                                   _ptr(query_vis, torch.uint8), _ptr(noise, torch.float32), n, _ptr(out), _ptr(valid), _ptr(knn), _stream()))
+    res = [out]
+    if want_valid:
+        res.append(valid)
+    if want_knn:
+        res.append(knn)
+    return res[0] if len(res) == 1 else tuple(res)
+
+
+def composite(rgba, z, mesh_sdf, beta, want_contrib=True):
+    """sdf_activation + rgba2out (src/model.py:879-882, 1464-1494).  rgba (R,S,5), z (R,S), mesh_sdf (R,S)."""
+    R, S = z.shape
+    dev = z.device
+    color = torch.empty(R, 3, dtype=torch.float32, device=dev)
+    depth, alpha, sdf = (torch.empty(R, dtype=torch.float32, device=dev) for _ in range(3))
+    contrib = torch.empty(R, S, dtype=torch.float32, device=dev) if want_contrib else None
+    check(lib.vanerf_composite(_ptr(rgba, torch.float32), _ptr(z, torch.float32), _ptr(mesh_sdf, torch.float32), R, S, float(beta),
+                               _ptr(color), _ptr(depth), _ptr(alpha), _ptr(sdf), _ptr(contrib), _stream()))
+    return color, depth, alpha, contrib, sdf
+
+
+def importance_merge(contrib, z, sample_per_ray, u=None, want_idx=False):
+    """importance_sample + sort-merge (src/model.py:1424-1462, 1301-1307).  contrib, z: (R,Sc) -> z_new (R,Sf), z_fine (R,Sc+Sf), src."""
+    R, Sc = z.shape
+    Sf = int(sample_per_ray)
+    dev = z.device
+    t_lin = torch.linspace(0.0, 1.0, steps=Sf).to(dev) if u is None else None
+    z_new = torch.empty(R, Sf, dtype=torch.float32, device=dev)
+    z_fine = torch.empty(R, Sc + Sf, dtype=torch.float32, device=dev)
+    src = torch.empty(R, Sc + Sf, dtype=torch.int32, device=dev)
+    idx = torch.empty(R, Sf, dtype=torch.int32, device=dev) if want_idx else None
+    check(lib.vanerf_importance_merge(_ptr(contrib, torch.float32), _ptr(z, torch.float32), _ptr(u, torch.float32), _ptr(t_lin), R, Sc, Sf,
+                                      _ptr(z_new), _ptr(z_fine), _ptr(src), _ptr(idx), _stream()))
+    return (z_new, z_fine, src, idx) if want_idx else (z_new, z_fine, src)
+
+
+def ray_setup(cam_tar, bounds, x0, y0, step, nx, ny, S, jitter=None, device=None):
+    """Pixel grid + rays + bbox clip + coarse depths (src/model.py:1191-1238, 1496-1570)."""
+    dev = device or bounds.device
+    K = cam_tar["K"].detach().to("cpu", torch.float32)
+    RT = cam_tar["RT"].detach().to("cpu", torch.float32)
+    inv_K_T = torch.inverse(K[:, :3, :3]).transpose(1, 2)[0].contiguous()  # th.inverse(...).transpose(1, 2), model.py:1208
+    R = nx * ny
+    index = torch.empty(R, dtype=torch.int64, device=dev)
+    rays_d = torch.empty(R, 3, dtype=torch.float32, device=dev)
+    cam_pos = torch.empty(3, dtype=torch.float32, device=dev)
+    near, far = torch.empty(R, dtype=torch.float32, device=dev), torch.empty(R, dtype=torch.float32, device=dev)
+    hit = torch.empty(R, dtype=torch.uint8, device=dev)
+    z = torch.empty(R, S, dtype=torch.float32, device=dev)
+    t_lin = torch.linspace(0.0, 1.0, steps=S).to(dev)
+    check(lib.vanerf_ray_setup(int(x0), int(y0), int(step), int(nx), int(ny), int(cam_tar["width"]), _farr(inv_K_T.reshape(-1).tolist(), 9),
+                               _farr(RT[0, :3, :4].reshape(-1).tolist(), 12), float(cam_tar["znear"]), float(cam_tar["zfar"]),
+                               _farr(bounds.detach().reshape(-1).tolist(), 6), int(S), _ptr(t_lin), _ptr(jitter, torch.float32),
+                               _ptr(index), _ptr(rays_d), _ptr(cam_pos), _ptr(near), _ptr(far), _ptr(hit), _ptr(z), _stream()))
+    return dict(index=index, rays_d=rays_d, cam_pos=cam_pos, near=near, far=far, hit=hit, z=z)
+
+
+def sample_points(rays_d, cam_pos, z):
+    R, S = z.shape
+    pts = torch.empty(R * S, 3, dtype=torch.float32, device=z.device)
+    check(lib.vanerf_sample_points(_ptr(rays_d, torch.float32), _ptr(cam_pos, torch.float32), _ptr(z, torch.float32), R, S, _ptr(pts), _stream()))
+    return pts
+
+
+# ------------------------------------------------------------------------------------------------
+# one pass: rays -> coarse march -> importance -> fine march (src/model.py:1102-1360)
+# ------------------------------------------------------------------------------------------------
+def render_pass(weights, frame, cam_tar, bounds, x0, y0, step, nx, ny, sample_per_ray_c=64, sample_per_ray_f=64, fine=True,
+                jitter=None, u=None, noise_std=0.0, generator=None, debug=False):
+    """Returns flat per-ray tensors: color/depth/alpha (coarse), color_fine/depth_fine/alpha_fine/sdf (fine), index, z, z_fine."""
+    Sc, Sf = int(sample_per_ray_c), int(sample_per_ray_f)
+    rays = ray_setup(cam_tar, bounds, x0, y0, step, nx, ny, Sc, jitter=jitter, device=frame.verts3.device)
+    R = nx * ny
+
+    def march(z):
+        S = z.shape[1]
+        pts = sample_points(rays["rays_d"], rays["cam_pos"], z)
+        q_sdf, q_vis = mesh_query(frame.verts3, frame.faces, frame.vert_vis, pts)
+        noise = None
+        if noise_std > 0.0:  # th.randn_like(rad) * rand_noise_std (src/model.py:1155-1156), drawn on the device
+            noise = torch.randn(pts.shape[0], device=pts.device, generator=generator) * noise_std
+        rgba = query_samples(weights, frame, pts, q_sdf, q_vis, noise)
+        color, depth, alpha, contrib, sdf = composite(rgba.view(R, S, 5), z, q_sdf.view(R, S), weights.beta)
+        return dict(pts=pts, q_sdf=q_sdf, q_vis=q_vis, rgba=rgba, color=color, depth=depth, alpha=alpha, contrib=contrib, sdf=sdf)
+
+    c = march(rays["z"])
+    out = {"color": c["color"], "depth": c["depth"], "alpha": c["alpha"], "index": rays["index"], "z": rays["z"], "hit": rays["hit"],
+           "rays_d": rays["rays_d"], "cam_pos": rays["cam_pos"]}
+    if debug:
+        out["coarse"] = c
+    if fine:
+        z_new, z_fine, src = importance_merge(c["contrib"], rays["z"], Sf, u=u)
+        f = march(z_fine)
+        out.update({"color_fine": f["color"], "depth_fine": f["depth"], "alpha_fine": f["alpha"], "sdf": f["sdf"], "z_fine": z_fine})
+        if debug:
+            out["fine"] = f
+    return out

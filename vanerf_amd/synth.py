@@ -210,3 +210,27 @@ def make_hot_weights(seed=0):
     sd["tex_vis_fusion.fconv_at.2.weight"] *= 2.0
     sd["tex_vis_fusion.fconv.2.weight"] *= 0.6
     return sd
+
+
+def make_texframe_weights():
+    """Per-frame TexVisFusion conv stack with the reference's init recipe (src/model.py:669-698): torch.manual_seed(125)
+    before each module, normal_(0, 0.02); LayerNorm affine = (1, 0)."""
+    shapes = {"fconv_gt.0.weight": (779, 42, 3), "fconv_gt.3.weight": (1558, 779, 3), "fconv3.0.weight": (21, 8, 3, 3),
+              "fconv3.3.weight": (42, 21, 3, 3), "fconv4.0.weight": (21, 3, 3, 3), "fconv4.3.weight": (42, 21, 3, 3)}
+    ln = {"fconv_gt.1": (18,), "fconv_gt.4": (18,), "fconv3.1": (64, 64), "fconv3.4": (64, 64), "fconv4.1": (256, 256), "fconv4.4": (256, 256)}
+    sd = {}
+    state = torch.get_rng_state()
+    for k, s in shapes.items():
+        torch.manual_seed(125)
+        sd["tex_vis_fusion." + k] = torch.empty(s).normal_(0.0, 0.02)
+    torch.set_rng_state(state)
+    for k, s in ln.items():
+        sd[f"tex_vis_fusion.{k}.weight"] = torch.ones(s)
+        sd[f"tex_vis_fusion.{k}.bias"] = torch.zeros(s)
+    return sd
+
+
+def make_full_weights(seed=0):
+    sd = make_hot_weights(seed)
+    sd.update(make_texframe_weights())
+    return sd
