@@ -1,0 +1,171 @@
+"""bench.py -- rendered rays/s of the VANeRF volume-rendering hot path on MI355X.
+
+One step = one pass of the hot path over one 512x334 target view (171 008 rays, 64 coarse + 64 importance
+samples per ray: the networks are evaluated on 192 points per ray, reference src/model.py:1289, 1345), with all
+frame inputs already resident in HBM.  With --gpus N the rays of the view are sharded across N ranks (interleaved
+rows, one process per GPU) and the fine RGB tiles are gathered with one RCCL all_gather (strong scaling: the view
+is the unit of work).  Rank 0 prints ONE JSON line.
+
+  python bench.py --gpus 1 --steps 5 --warmup 2
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import statistics
+import sys
+import time
+
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+FLOP_PER_SAMPLE = 2 * 143772          # 143 772 MAC per sample evaluation (V = 1)
+PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+
+
+def usable_cores():
+    """Host cores this process may actually use: affinity mask capped by the cgroup CPU quota (a GPU box hands each
+    job a share of the host, typically 16 cores per GPU, while os.cpu_count() still reports the whole machine)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // p))
+        except (OSError, ValueError):
+            pass
+    return min(n, int(os.environ.get("VANERF_CPU_THREADS", "16")))
+
+
+def cpu_baseline(sd, frame, S, rays_side):
+    """The oracle (a PyTorch-CPU port of the reference renderer, same unfused op sequence) on a bounded sample of the
+    same workload: a strided rays_side x rays_side grid of the 512x334 view at 64+64 samples."""
+    from oracle import vanerf_oracle as orc
+    W, H = frame["cam_tar"]["width"], frame["cam_tar"]["height"]
+    sx, sy = W // rays_side, H // rays_side
+    gy, gx = torch.meshgrid(torch.arange(rays_side) * sy + sy // 2, torch.arange(rays_side) * sx + sx // 2, indexing="ij")
+    grids = torch.stack([gx, gy], -1).view(1, -1, 2)
+    fr = dict(frame)
+    fr["out_hw"] = (rays_side, rays_side)
+    cores = usable_cores()
+    os.environ["OMP_NUM_THREADS"] = str(cores)  # read by the oracle's C library (OpenMP) when it is first loaded
+    torch.set_num_threads(cores)
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        out = orc.batch_render(sd, fr, 1, None, S, S, grids=grids)
+    dt = time.perf_counter() - t0
+    n = rays_side * rays_side
+    return {"value": n / dt, "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{rays_side}x{rays_side} strided rays of the 512x334 view, {S}+{S} samples/ray, {dt:.1f} s"}, out, grids
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--height", type=int, default=512)
+    ap.add_argument("--width", type=int, default=334)
+    ap.add_argument("--samples", type=int, default=64)
+    ap.add_argument("--cpu-rays-side", type=int, default=40, help="cpu_baseline sample: side of the strided ray grid (0 = skip)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    from vanerf_amd import renderer, synth
+    from vanerf_amd.parallel import shard_rows
+
+    S, H, W = args.samples, args.height, args.width
+    sd = synth.make_full_weights(0)
+    frame = synth.make_frame(seed=11, tar_h=H, tar_w=W, orbit_deg=15.0)
+    fd = synth.to_device(frame, "cuda")
+    sdd = {k: v.cuda() for k, v in sd.items() if k.startswith("tex_vis_fusion.")}
+    fdat = renderer.FrameData(sdd, fd["img_in"], fd["feat_geo"], fd["feat_tex"], fd["src_foreground_mask"], fd["cam_in"], fd["targets"], fd["sp_data"])
+    weights = renderer.PackedWeights(sd)
+    rows = shard_rows(H, world, rank)  # (y0, step, ny): interleaved rows -> even load
+    events = []
+
+    def step(record=None):
+        out = renderer.render_pass(weights, fdat, frame["cam_tar"], frame["bounds"], 0, rows[0], 1, W, rows[2], S, S,
+                                   kernel_events=record, y_step=rows[1])
+        tile = out["color_fine"]
+        if world > 1:
+            full = torch.empty(world * tile.shape[0], 3, device=tile.device)
+            dist.all_gather_into_tensor(full, tile)
+            return full
+        return tile
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        img = step(events)
+    barrier()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+
+    # dominant kernel: query_kernel, two launches per step (coarse R*S and fine R*2S samples)
+    k_ms = [e0.elapsed_time(e1) for e0, e1, _ in events]
+    k_samples = [n for _, _, n in events]
+    kern_s = sum(k_ms) / 1e3
+    achieved = sum(k_samples) * FLOP_PER_SAMPLE / kern_s / 1e12
+    rays_total = H * W
+    result = {
+        "metric": "rendered rays/sec (64 samples/ray) + PSNR vs ref, 512x334 view", "value": rays_total * args.steps / dt, "unit": "rays/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"configs/vanerf.json eval view {H}x{W}, {S} coarse + {S} importance samples/ray (192 network evaluations/ray), "
+                               "two-hand mesh 1558 verts / 3108 faces, 1 source view 256x256, random trained-like weights",
+                   "rays": rays_total, "parallelism": f"rays{world}" if world > 1 else "single"},
+        "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
+                     "traffic": None, "kernel": "query_kernel (v_mfma_f32_32x32x2_f32)", "launches": len(events),
+                     "avg_launch_ms": statistics.mean(k_ms), "kernel_ms_per_step": sum(k_ms) / args.steps,
+                     "flop_per_launch_avg": sum(k_samples) * FLOP_PER_SAMPLE / len(events)},
+    }
+    if rank == 0 and world == 1 and args.cpu_rays_side > 0:
+        base, ref, grids = cpu_baseline(sd, frame, S, args.cpu_rays_side)
+        result["cpu_baseline"] = base
+        # PSNR of the rendered view against the CPU oracle on the sampled pixels (src/evaluator.py:16-19)
+        from oracle import vanerf_oracle as orc
+        idx = (grids[0, :, 0] + grids[0, :, 1] * W).long()
+        got = img.view(H * W, 3)[idx.cuda()].cpu()
+        want = ref["tex_fg_fine"][0].reshape(3, -1).t()
+        err = (got - want).abs()
+        result["parity"] = {"psnr_db": orc.psnr(got, want), "max_abs_err": err.max().item(),
+                            "frac_pixels_above_1e-4": (err.max(1)[0] > 1e-4).float().mean().item(), "pixels": int(idx.numel())}
+        result["speedup_vs_cpu"] = result["value"] / base["value"]
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -16,6 +16,10 @@ from vanerf_amd import synth
 pytestmark = pytest.mark.gpu
 
 TOL = 1e-4
+# Whole-image comparisons: sample positions differ in the last bit between torch-CPU and the HIP ray generator (about 25 %
+# of the points), and the renderer's arg-min / threshold decisions (closest face on a shared edge, visibility >= 0.1,
+# 1-NN) turn that into an O(0.1) change of about 1e-5 of the samples -> a few pixels per thousand (tools/diag_flips.py).
+OUTLIERS = 5e-3
 
 
 @pytest.fixture(scope="module")
@@ -205,7 +209,7 @@ def test_query_samples_vs_reference_golden(R, sd_full, golden):
     g = golden("query")
     frame = synth.make_frame(seed=3, tar_h=64, tar_w=64, half_mask=True)
     fdat = _frame_data(R, sd_full, frame)
-    assert (fdat.vfeat_tex.cpu()[:, :29] - g["vert_feat29"][0] * g["vert_vis"][0]).abs().max() <= 1e-5
+    assert (fdat.vfeat_tex.cpu()[:, :29] - g["vert_feat29"][0] * g["vert_vis"][0]).abs().max() <= 1e-4  # MIOpen convs vs CPU, values up to ~3
     w = R.PackedWeights(sd_full)
     got, gvalid = R.query_samples(w, fdat, dev(g["pts"][0].contiguous()), dev(g["q_sdf"][0].contiguous()),
                                   dev(g["q_vis"][0, :, 0].to(torch.uint8).contiguous()), want_valid=True)
@@ -230,10 +234,10 @@ def test_render_pass_vs_reference_golden(R, sd_full, golden, tag, seed, hw, orbi
     out = R.render_pass(w, fdat, cam, frame["bounds"], off[0], off[1], step, n, n, S, S)
     for k, gk in (("color", "tex_fg"), ("color_fine", "tex_fg_fine")):
         got = out[k].cpu().view(n, n, 3).permute(2, 0, 1)
-        err, bad = assert_close_frac(got, g[gk][0], TOL, 1e-3, gk)
+        err, bad = assert_close_frac(got, g[gk][0], TOL, OUTLIERS, gk)
         print(tag, gk, "max abs err", err, "outliers", bad, "psnr", orc.psnr(got, g[gk][0]))
     for k, gk in (("depth", "depth"), ("alpha", "alpha"), ("depth_fine", "depth_fine"), ("alpha_fine", "alpha_fine"), ("sdf", "sdf")):
-        assert_close_frac(out[k].cpu().view(n, n), g[gk][0], TOL, 1e-3, gk)
+        assert_close_frac(out[k].cpu().view(n, n), g[gk][0], TOL, OUTLIERS, gk)
     assert torch.equal(fdat.vert_vis.cpu(), g["vert_vis"][0, :, 0])
 
 
@@ -251,10 +255,10 @@ def test_render_pass_vs_oracle_benchmark_shape(R, sd_full):
     ref = orc.batch_render(sd_full, fr, 1, None, 64, 64, grids=grids)
     assert torch.equal(out["index"].cpu(), ref["index"][0])
     got = out["color_fine"].cpu().view(ny, nx, 3).permute(2, 0, 1)
-    err, bad = assert_close_frac(got, ref["tex_fg_fine"][0], TOL, 1e-3, "tex_fg_fine")
+    err, bad = assert_close_frac(got, ref["tex_fg_fine"][0], TOL, OUTLIERS, "tex_fg_fine")
     print("512x334 slice: max abs err", err, "outliers", bad, "psnr", orc.psnr(got, ref["tex_fg_fine"][0]))
     assert orc.psnr(got, ref["tex_fg_fine"][0]) > 80.0
-    assert_close_frac(out["depth_fine"].cpu().view(ny, nx), ref["depth_fine"][0], TOL, 1e-3, "depth_fine")
+    assert_close_frac(out["depth_fine"].cpu().view(ny, nx), ref["depth_fine"][0], TOL, OUTLIERS, "depth_fine")
 
 
 def test_full_view_properties(R, sd_full):

@@ -48,7 +48,7 @@ _SIGS = {
     "vanerf_weights_pack": (c_int, [POINTER(VanerfWeightTable), c_int, POINTER(c_void_p)]),
     "vanerf_weights_free": (c_int, [c_void_p]),
     "vanerf_weights_pack_host": (c_int, [POINTER(VanerfWeightTable), _FP, c_int64, POINTER(c_int64), POINTER(c_uint)]),
-    "vanerf_ray_setup": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, POINTER(c_float), POINTER(c_float), c_float, c_float,
+    "vanerf_ray_setup": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, POINTER(c_float), POINTER(c_float), c_float, c_float,
                                  POINTER(c_float), c_int, _FP, _FP, _FP, _FP, _FP, _FP, _FP, _FP, _FP, c_void_p]),
     "vanerf_sample_points": (c_int, [_FP, _FP, _FP, c_int, c_int, _FP, c_void_p]),
     "vanerf_vertex_visibility": (c_int, [_FP, _FP, c_int, _FP, c_int, c_int, _FP, _FP, c_void_p]),

@@ -12,7 +12,7 @@ using namespace vanerf;
 namespace {
 
 struct RayParams {
-    int x0, y0, step, nx, ny, width;
+    int x0, y0, step_x, step_y, nx, ny, width;
     float invK_T[9];
     float RT[12];
     float znear, zfar;
@@ -44,7 +44,7 @@ __global__ void ray_setup_kernel(const RayParams P)
     if (r == 0) { P.cam_pos[0] = ox; P.cam_pos[1] = oy; P.cam_pos[2] = oz; }
     if (r >= R) return;
     const int ix = r % P.nx, iy = r / P.nx;
-    const int gxi = P.x0 + ix * P.step, gyi = P.y0 + iy * P.step;
+    const int gxi = P.x0 + ix * P.step_x, gyi = P.y0 + iy * P.step_y;
     P.index[r] = (int64_t)gxi + (int64_t)gyi * P.width;
     const float gx = (float)gxi, gy = (float)gyi;
     const float* K = P.invK_T; // row-major 3x3: c_j = gx*K[0][j] + gy*K[1][j] + K[2][j]
@@ -243,7 +243,7 @@ __global__ __launch_bounds__(IM_BLOCK) void importance_merge_kernel(const float*
 
 } // namespace
 
-extern "C" int vanerf_ray_setup(int x0, int y0, int step, int nx, int ny, int width, const float* invK_T, const float* RT,
+extern "C" int vanerf_ray_setup(int x0, int y0, int step_x, int step_y, int nx, int ny, int width, const float* invK_T, const float* RT,
                                 float znear, float zfar, const float* bounds, int S, const float* t_lin, const float* jitter,
                                 int64_t* index, float* rays_d, float* cam_pos, float* near, float* far, uint8_t* hit, float* z,
                                 void* stream)
@@ -251,9 +251,10 @@ extern "C" int vanerf_ray_setup(int x0, int y0, int step, int nx, int ny, int wi
     return guarded([&] {
         if (!invK_T || !RT || !bounds || !t_lin || !index || !rays_d || !cam_pos || !near || !far || !hit || !z)
             throw_error("vanerf_ray_setup: null argument");
-        if (nx <= 0 || ny <= 0 || step <= 0 || S < 2 || width <= 0) throw_error("vanerf_ray_setup: bad grid (nx=%d ny=%d step=%d S=%d)", nx, ny, step, S);
+        if (nx <= 0 || ny <= 0 || step_x <= 0 || step_y <= 0 || S < 2 || width <= 0)
+            throw_error("vanerf_ray_setup: bad grid (nx=%d ny=%d step=%d,%d S=%d)", nx, ny, step_x, step_y, S);
         RayParams P;
-        P.x0 = x0; P.y0 = y0; P.step = step; P.nx = nx; P.ny = ny; P.width = width;
+        P.x0 = x0; P.y0 = y0; P.step_x = step_x; P.step_y = step_y; P.nx = nx; P.ny = ny; P.width = width;
         std::copy_n(invK_T, 9, P.invK_T);
         std::copy_n(RT, 12, P.RT);
         std::copy_n(bounds, 6, P.bounds);

@@ -100,7 +100,7 @@ class PackedWeights:
         self.beta = max(float(tab.sigmoid_beta), 2e-3)  # sdf_activation clamp (src/model.py:880)
 
     def close(self):
-        if getattr(self, "handle", None):
+        if getattr(self, "handle", None) and lib is not None:  # `lib` is None during interpreter shutdown
             lib.vanerf_weights_free(self.handle)
             self.handle = None
 
@@ -290,7 +290,7 @@ def importance_merge(contrib, z, sample_per_ray, u=None, want_idx=False):
     return (z_new, z_fine, src, idx) if want_idx else (z_new, z_fine, src)
 
 
-def ray_setup(cam_tar, bounds, x0, y0, step, nx, ny, S, jitter=None, device=None):
+def ray_setup(cam_tar, bounds, x0, y0, step, nx, ny, S, jitter=None, device=None, y_step=None):
     """Pixel grid + rays + bbox clip + coarse depths (src/model.py:1191-1238, 1496-1570)."""
     dev = device or bounds.device
     K = cam_tar["K"].detach().to("cpu", torch.float32)
@@ -304,7 +304,7 @@ def ray_setup(cam_tar, bounds, x0, y0, step, nx, ny, S, jitter=None, device=None
     hit = torch.empty(R, dtype=torch.uint8, device=dev)
     z = torch.empty(R, S, dtype=torch.float32, device=dev)
     t_lin = torch.linspace(0.0, 1.0, steps=S).to(dev)
-    check(lib.vanerf_ray_setup(int(x0), int(y0), int(step), int(nx), int(ny), int(cam_tar["width"]), _farr(inv_K_T.reshape(-1).tolist(), 9),
+    check(lib.vanerf_ray_setup(int(x0), int(y0), int(step), int(y_step or step), int(nx), int(ny), int(cam_tar["width"]), _farr(inv_K_T.reshape(-1).tolist(), 9),
                                _farr(RT[0, :3, :4].reshape(-1).tolist(), 12), float(cam_tar["znear"]), float(cam_tar["zfar"]),
                                _farr(bounds.detach().reshape(-1).tolist(), 6), int(S), _ptr(t_lin), _ptr(jitter, torch.float32),
                                _ptr(index), _ptr(rays_d), _ptr(cam_pos), _ptr(near), _ptr(far), _ptr(hit), _ptr(z), _stream()))
@@ -322,10 +322,10 @@ def sample_points(rays_d, cam_pos, z):
 # one pass: rays -> coarse march -> importance -> fine march (src/model.py:1102-1360)
 # ------------------------------------------------------------------------------------------------
 def render_pass(weights, frame, cam_tar, bounds, x0, y0, step, nx, ny, sample_per_ray_c=64, sample_per_ray_f=64, fine=True,
-                jitter=None, u=None, noise_std=0.0, generator=None, debug=False):
+                jitter=None, u=None, noise_std=0.0, generator=None, debug=False, kernel_events=None, y_step=None):
     """Returns flat per-ray tensors: color/depth/alpha (coarse), color_fine/depth_fine/alpha_fine/sdf (fine), index, z, z_fine."""
     Sc, Sf = int(sample_per_ray_c), int(sample_per_ray_f)
-    rays = ray_setup(cam_tar, bounds, x0, y0, step, nx, ny, Sc, jitter=jitter, device=frame.verts3.device)
+    rays = ray_setup(cam_tar, bounds, x0, y0, step, nx, ny, Sc, jitter=jitter, device=frame.verts3.device, y_step=y_step)
     R = nx * ny
 
     def march(z):
@@ -335,7 +335,13 @@ def render_pass(weights, frame, cam_tar, bounds, x0, y0, step, nx, ny, sample_pe
         noise = None
         if noise_std > 0.0:  # th.randn_like(rad) * rand_noise_std (src/model.py:1155-1156), drawn on the device
             noise = torch.randn(pts.shape[0], device=pts.device, generator=generator) * noise_std
+        if kernel_events is not None:  # HIP events around the dominant kernel, on the stream it is launched on
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         rgba = query_samples(weights, frame, pts, q_sdf, q_vis, noise)
+        if kernel_events is not None:
+            e1.record()
+            kernel_events.append((e0, e1, pts.shape[0]))
         color, depth, alpha, contrib, sdf = composite(rgba.view(R, S, 5), z, q_sdf.view(R, S), weights.beta)
         return dict(pts=pts, q_sdf=q_sdf, q_vis=q_vis, rgba=rgba, color=color, depth=depth, alpha=alpha, contrib=contrib, sdf=sdf)
 

@@ -233,4 +233,23 @@ def make_texframe_weights():
 def make_full_weights(seed=0):
     sd = make_hot_weights(seed)
     sd.update(make_texframe_weights())
+    sd.update(make_ibr_weights(seed))
+    return sd
+
+
+IBR_SHAPES = {
+    "ray_encoder.0": (16, 4), "ray_encoder.2": (40, 16), "base_layer.0": (64, 120), "base_layer.2": (32, 64),
+    "vis_layer1.0": (32, 32), "vis_layer1.2": (33, 32), "vis_layer2.0": (32, 32), "vis_layer2.2": (1, 32),
+    "out_layer.0": (16, 37), "out_layer.2": (8, 16), "out_layer.4": (1, 8),
+}
+
+
+def make_ibr_weights(seed=0):
+    """IBRRenderingHead parameters (src/model.py:1575-1591).  At V = 1 the head returns rgb_feat[..., :3] exactly
+    (softmax over one view), so these only matter to the oracle's restatement and to state_dict completeness."""
+    g = torch.Generator().manual_seed(2000 + seed)
+    sd = {"mlp_tex.ani_al": torch.tensor(0.2)}
+    for k, (o, i) in IBR_SHAPES.items():
+        sd[f"mlp_tex.{k}.weight"] = torch.randn(o, i, generator=g) * math.sqrt(2.0 / i)
+        sd[f"mlp_tex.{k}.bias"] = torch.zeros(o)
     return sd
