@@ -128,6 +128,23 @@ int vanerf_vertex_visibility(const float* vert_xy01, const float* vert_z01, int 
 int vanerf_mesh_query(const float* verts, int nv, const int32_t* faces, int nf, const float* vert_vis,
                       const float* pts, int64_t n, float* sdf, uint8_t* vis, int32_t* face, void* stream);
 
+/* Acceleration structure for vanerf_mesh_query_accel (built per source frame on the device by the caller, see
+ * vanerf_amd/renderer.py:MeshAccel).  Results are bit-identical to vanerf_mesh_query.                                   */
+typedef struct {
+    const float* tri;          /* [nfp][9]  triangle corners, Morton-sorted, padded to a multiple of 16 with far-away triangles */
+    const float* sphere;       /* [nfp][4]  bounding sphere of each triangle (centre, radius) */
+    const int32_t* orig;       /* [nfp]     original face index (INT32_MAX for padding) */
+    const float* cbox;         /* [nc][6]   AABB of each cluster of 16 triangles (lo xyz, hi xyz) */
+    int nfp, nc;
+    const int32_t* cell_start; /* [G*G + 1] CSR offsets of the (y,z) grid used by the inside test */
+    const int32_t* cell_tri;   /* original face ids per cell */
+    int G;
+    float y0, z0, cell_y, cell_z;
+} VanerfMeshAccel;
+
+int vanerf_mesh_query_accel(const VanerfMeshAccel* accel, const float* verts, int nv, const int32_t* faces, int nf,
+                            const float* vert_vis, const float* pts, int64_t n, float* sdf, uint8_t* vis, int32_t* face, void* stream);
+
 /* a10 knn_points K=1 (src/networks.py:28): verts[NV][4], pts[N][3] -> idx[N] int32 (first minimum). */
 int vanerf_knn1(const float* verts4, int nv, const float* pts, int64_t n, int32_t* idx, void* stream);
 

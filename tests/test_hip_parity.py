@@ -96,6 +96,24 @@ def test_mesh_query_bit_exact(R):
     assert 0.05 < (sdf < 0).float().mean() < 0.95
 
 
+def test_mesh_query_accel_equals_brute_force(R):
+    """The cluster / grid accelerated query must reproduce the exhaustive scan bit for bit (near, far and on-vertex points)."""
+    for seed in (3, 11):
+        frame = _frame(seed, 64)
+        verts = dev(frame["targets"]["vert_world"][0].contiguous())
+        faces = dev(frame["targets"]["face_world"][0].to(torch.int32))
+        g = torch.Generator().manual_seed(seed)
+        near = _points_near_mesh(frame, 40000, seed=seed)
+        far = frame["targets"]["vert_world"][0].mean(0) + torch.randn(20000, 3, generator=g) * torch.tensor([0.15, 0.15, 0.3])
+        p = dev(torch.cat([near, far], 0).contiguous())
+        vv = dev((torch.rand(verts.shape[0], generator=g) > 0.5).float())
+        accel = R.MeshAccel(verts, faces)
+        s0, v0, f0 = R.mesh_query(verts, faces, vv, p, want_face=True)
+        s1, v1, f1 = R.mesh_query_accel(accel, verts, faces, vv, p, want_face=True)
+        assert torch.equal(s0, s1) and torch.equal(v0, v1) and torch.equal(f0, f1)
+        assert 0.02 < (s0 < 0).float().mean() < 0.9
+
+
 def test_ray_setup(R):
     for seed, hw, tw, step, off in ((3, 64, 64, 8, (3, 5)), (11, 512, 334, 2, (1, 0))):
         frame = _frame(seed, hw, 15.0, tar_w=tw)

@@ -42,6 +42,13 @@ class VanerfFrame(Structure):
     ]
 
 
+class VanerfMeshAccel(Structure):
+    _fields_ = [
+        ("tri", _FP), ("sphere", _FP), ("orig", _FP), ("cbox", _FP), ("nfp", c_int), ("nc", c_int),
+        ("cell_start", _FP), ("cell_tri", _FP), ("G", c_int), ("y0", c_float), ("z0", c_float), ("cell_y", c_float), ("cell_z", c_float),
+    ]
+
+
 _SIGS = {
     "vanerf_abi_version": (c_int, []),
     "vanerf_last_error": (c_char_p, []),
@@ -53,6 +60,7 @@ _SIGS = {
     "vanerf_sample_points": (c_int, [_FP, _FP, _FP, c_int, c_int, _FP, c_void_p]),
     "vanerf_vertex_visibility": (c_int, [_FP, _FP, c_int, _FP, c_int, c_int, _FP, _FP, c_void_p]),
     "vanerf_mesh_query": (c_int, [_FP, c_int, _FP, c_int, _FP, _FP, c_int64, _FP, _FP, _FP, c_void_p]),
+    "vanerf_mesh_query_accel": (c_int, [POINTER(VanerfMeshAccel), _FP, c_int, _FP, c_int, _FP, _FP, c_int64, _FP, _FP, _FP, c_void_p]),
     "vanerf_knn1": (c_int, [_FP, c_int, _FP, c_int64, _FP, c_void_p]),
     "vanerf_query_samples": (c_int, [c_void_p, POINTER(VanerfFrame), _FP, _FP, _FP, _FP, c_int64, _FP, _FP, _FP, c_void_p]),
     "vanerf_composite": (c_int, [_FP, _FP, _FP, c_int, c_int, c_float, _FP, _FP, _FP, _FP, _FP, c_void_p]),

@@ -218,6 +218,120 @@ __global__ __launch_bounds__(256) void knn1_kernel(const float4* __restrict__ ve
     idx[i] = bi;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Accelerated cal_vis_sdf_batch: identical results to mesh_query_kernel (same per-triangle arithmetic), but
+//   * closest face: triangles are Morton-sorted into clusters of 16 with an AABB per cluster and a bounding sphere
+//     per triangle; a cluster / triangle is skipped only when its distance lower bound exceeds the best distance so
+//     far by a safety margin (1e-4 relative: far above fp32 rounding), so the exact minimum and every tie survive;
+//     ties resolve to the lowest ORIGINAL face index, as the brute-force scan does;
+//   * inside test: a G x G grid over the mesh's (y,z) extent lists the triangles whose (y,z) bounding box touches each
+//     cell; the +x ray of a point can only cross triangles of its own cell.
+// The structure is built per source frame by vanerf_amd/renderer.py:MeshAccel (torch on the device).
+constexpr int CL = 16; // triangles per cluster
+constexpr int MA_BLOCK = 256;
+constexpr int MA_MAX_CLUSTERS = 1024;
+
+__device__ __forceinline__ float box_dist2(f3 p, const float* b)
+{
+    const float dx = fmaxf(fmaxf(b[0] - p.x, p.x - b[3]), 0.0f);
+    const float dy = fmaxf(fmaxf(b[1] - p.y, p.y - b[4]), 0.0f);
+    const float dz = fmaxf(fmaxf(b[2] - p.z, p.z - b[5]), 0.0f);
+    return (dx * dx + dy * dy) + dz * dz;
+}
+
+__global__ __launch_bounds__(MA_BLOCK) void mesh_query_accel_kernel(const VanerfMeshAccel A, const float* __restrict__ V,
+                                                                    const int32_t* __restrict__ F, const float* __restrict__ vert_vis,
+                                                                    const float* __restrict__ P, long long n, float* __restrict__ sdf,
+                                                                    uint8_t* __restrict__ vis, int32_t* __restrict__ face)
+{
+    __shared__ float s_box[MA_MAX_CLUSTERS * 6];
+    for (int k = threadIdx.x; k < A.nc * 6; k += MA_BLOCK) s_box[k] = A.cbox[k];
+    __syncthreads();
+    for (long long i = (long long)blockIdx.x * MA_BLOCK + threadIdx.x; i < n; i += (long long)gridDim.x * MA_BLOCK) {
+        const f3 p = {P[3 * i], P[3 * i + 1], P[3 * i + 2]};
+        float best = INFINITY;
+        int bf = 0x7fffffff;
+        auto eval_cluster = [&](int c, bool filter) {
+            const float bound = best * (1.0f + 1e-4f) + 1e-12f;
+            for (int k = 0; k < CL; ++k) {
+                const int t = c * CL + k;
+                if (filter) {
+                    const float4 sp = reinterpret_cast<const float4*>(A.sphere)[t];
+                    const float ex = p.x - sp.x, ey = p.y - sp.y, ez = p.z - sp.z;
+                    const float g = fmaxf(sqrtf((ex * ex + ey * ey) + ez * ez) - sp.w, 0.0f);
+                    if (g * g > bound) continue;
+                }
+                const float* q = A.tri + (size_t)t * 9;
+                const f3 a = {q[0], q[1], q[2]}, b = {q[3], q[4], q[5]}, c3 = {q[6], q[7], q[8]};
+                const float d = point_tri_dist2(p, a, b, c3);
+                const int of = A.orig[t];
+                if (d < best || (d == best && of < bf)) { best = d; bf = of; }
+            }
+        };
+        // pass 1: the cluster with the smallest lower bound seeds `best`
+        float lmin = INFINITY;
+        int cmin = 0;
+        for (int c = 0; c < A.nc; ++c) {
+            const float lb = box_dist2(p, s_box + 6 * c);
+            if (lb < lmin) { lmin = lb; cmin = c; }
+        }
+        eval_cluster(cmin, false);
+        // pass 2: every cluster that can still hold the minimum (or a tie)
+        for (int c = 0; c < A.nc; ++c) {
+            if (c == cmin) continue;
+            const float lb = box_dist2(p, s_box + 6 * c);
+            if (lb > best * (1.0f + 1e-4f) + 1e-12f) continue;
+            eval_cluster(c, true);
+        }
+        // inside test on the (y,z) grid
+        int cnt = 0;
+        {
+            int cy = (int)floorf((p.y - A.y0) / A.cell_y), cz = (int)floorf((p.z - A.z0) / A.cell_z);
+            cy = min(max(cy, 0), A.G - 1);
+            cz = min(max(cz, 0), A.G - 1);
+            const int cell = cy * A.G + cz;
+            const int e = A.cell_start[cell + 1];
+            for (int k = A.cell_start[cell]; k < e; ++k) {
+                const int f = A.cell_tri[k];
+                const int i0 = F[3 * f], i1 = F[3 * f + 1], i2 = F[3 * f + 2];
+                const f3 a = {V[3 * i0], V[3 * i0 + 1], V[3 * i0 + 2]}, b = {V[3 * i1], V[3 * i1 + 1], V[3 * i1 + 2]},
+                         c3 = {V[3 * i2], V[3 * i2 + 1], V[3 * i2 + 2]};
+                float E0, E1, E2;
+                const bool s0 = edge_side(b, c3, i1, i2, p.y, p.z, E0);
+                const bool s1 = edge_side(c3, a, i2, i0, p.y, p.z, E1);
+                const bool s2 = edge_side(a, b, i0, i1, p.y, p.z, E2);
+                if ((s0 && s1 && s2) || (!s0 && !s1 && !s2)) {
+                    const float den = (E0 + E1) + E2;
+                    if (den != 0.0f) {
+                        const float xh = ((E0 * a.x + E1 * b.x) + E2 * c3.x) / den;
+                        if (xh > p.x) ++cnt;
+                    }
+                }
+            }
+        }
+        const float dist = sqrtf(best + 1e-6f);
+        sdf[i] = (cnt & 1) ? -dist : dist;
+        if (face) face[i] = bf;
+        const int i0 = F[3 * bf], i1 = F[3 * bf + 1], i2 = F[3 * bf + 2];
+        const f3 v0 = {V[3 * i0], V[3 * i0 + 1], V[3 * i0 + 2]}, v1 = {V[3 * i1], V[3 * i1 + 1], V[3 * i1 + 2]},
+                 v2 = {V[3 * i2], V[3 * i2 + 1], V[3 * i2 + 2]};
+        const f3 u = sub3(v1, v0), v = sub3(v2, v0);
+        const f3 nrm = {u.y * v.z - u.z * v.y, u.z * v.x - u.x * v.z, u.x * v.y - u.y * v.x};
+        float s = dot3(nrm, nrm);
+        if (s == 0.0f) s = 1e-6f;
+        const float inv = 1.0f / s;
+        const f3 wv = sub3(p, v0);
+        const f3 c1 = {u.y * wv.z - u.z * wv.y, u.z * wv.x - u.x * wv.z, u.x * wv.y - u.y * wv.x};
+        const f3 c2 = {wv.y * v.z - wv.z * v.y, wv.z * v.x - wv.x * v.z, wv.x * v.y - wv.y * v.x};
+        const float b2 = dot3(c1, nrm) * inv;
+        const float b1 = dot3(c2, nrm) * inv;
+        const float w0 = (1.0f - b1) - b2;
+        const float sv = (w0 * vert_vis[i0] + b1 * vert_vis[i1]) + b2 * vert_vis[i2];
+        vis[i] = sv >= 0.1f;
+    }
+}
+
 } // namespace
 
 extern "C" int vanerf_vertex_visibility(const float* vert_xy01, const float* vert_z01, int nv, const int32_t* faces, int nf,
@@ -256,6 +370,26 @@ extern "C" int vanerf_knn1(const float* verts4, int nv, const float* pts, int64_
         if (n == 0) return;
         hipLaunchKernelGGL(knn1_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), sizeof(float4) * nv, (hipStream_t)stream,
                            reinterpret_cast<const float4*>(verts4), nv, pts, (long long)n, idx);
+        HIP_CHECK(hipGetLastError());
+    });
+}
+
+extern "C" int vanerf_mesh_query_accel(const VanerfMeshAccel* accel, const float* verts, int nv, const int32_t* faces, int nf,
+                                       const float* vert_vis, const float* pts, int64_t n, float* sdf, uint8_t* vis, int32_t* face,
+                                       void* stream)
+{
+    return guarded([&] {
+        if (!accel || !verts || !faces || !vert_vis || !pts || !sdf || !vis) throw_error("vanerf_mesh_query_accel: null argument");
+        const VanerfMeshAccel& A = *accel;
+        if (!A.tri || !A.sphere || !A.orig || !A.cbox || !A.cell_start || !A.cell_tri) throw_error("vanerf_mesh_query_accel: accel has a null pointer");
+        if (A.nc <= 0 || A.nc > MA_MAX_CLUSTERS || A.nfp != A.nc * CL || A.nfp < nf) throw_error("vanerf_mesh_query_accel: bad cluster table (nc=%d nfp=%d nf=%d)", A.nc, A.nfp, nf);
+        if (A.G <= 0 || !(A.cell_y > 0.0f) || !(A.cell_z > 0.0f)) throw_error("vanerf_mesh_query_accel: bad grid");
+        if (nv <= 0 || nf <= 0 || n < 0) throw_error("vanerf_mesh_query_accel: nv=%d nf=%d n=%lld", nv, nf, (long long)n);
+        if (n == 0) return;
+        long long blocks = (n + MA_BLOCK - 1) / MA_BLOCK;
+        if (blocks > 256 * 8) blocks = 256 * 8;
+        hipLaunchKernelGGL(mesh_query_accel_kernel, dim3((unsigned)blocks), dim3(MA_BLOCK), 0, (hipStream_t)stream, A, verts, faces, vert_vis,
+                           pts, (long long)n, sdf, vis, face);
         HIP_CHECK(hipGetLastError());
     });
 }

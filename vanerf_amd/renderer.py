@@ -13,7 +13,7 @@ import torch
 import torch.nn.functional as F
 
 from . import _ffi
-from ._ffi import VanerfFrame, VanerfWeightTable, check, lib
+from ._ffi import VanerfFrame, VanerfMeshAccel, VanerfWeightTable, check, lib
 
 NV, NV_HAND, NKPT = 1558, 779, 42
 
@@ -149,6 +149,70 @@ def tex_global_vertex_feature(sd, feat_tex, img, pre="tex_vis_fusion."):
     return torch.relu(F.layer_norm(x, [18], sd[pre + "fconv_gt.4.weight"], sd[pre + "fconv_gt.4.bias"], 1e-6))
 
 
+def _part1by2(x):
+    x = (x | (x << 16)) & 0x030000FF
+    x = (x | (x << 8)) & 0x0300F00F
+    x = (x | (x << 4)) & 0x030C30C3
+    return (x | (x << 2)) & 0x09249249
+
+
+class MeshAccel:
+    """Per-frame acceleration structure of vanerf_mesh_query_accel, built with torch ops on the device:
+    Morton-sorted triangle clusters (closest-face search) and a (y,z) cell grid (inside test)."""
+    CL = 16
+
+    def __init__(self, verts3, faces_i32, grid=64):
+        dev = verts3.device
+        nf = faces_i32.shape[0]
+        tri = verts3[faces_i32.long()]  # (NF,3,3)
+        lo, hi = verts3.min(0)[0], verts3.max(0)[0]
+        q = ((tri.mean(1) - lo) / (hi - lo + 1e-9) * 1023.0).long().clamp(0, 1023)
+        code = _part1by2(q[:, 0]) | (_part1by2(q[:, 1]) << 1) | (_part1by2(q[:, 2]) << 2)
+        order = torch.argsort(code, stable=True)
+        nfp = (nf + self.CL - 1) // self.CL * self.CL
+        pad = nfp - nf
+        tri_s = tri[order]
+        if pad:  # far-away triangles that can never be the closest
+            far = torch.full((pad, 3, 3), 1.0e4, device=dev) + torch.arange(3, device=dev, dtype=torch.float32)[None, :, None]
+            tri_s = torch.cat([tri_s, far], 0)
+        self.tri = tri_s.reshape(nfp, 9).contiguous()
+        self.orig = torch.cat([order.to(torch.int32), torch.full((pad,), 0x7FFFFFFF, dtype=torch.int32, device=dev)]).contiguous()
+        cen = tri_s.mean(1)
+        rad = (tri_s - cen[:, None]).norm(dim=-1).max(1)[0] * (1.0 + 1e-5) + 1e-9
+        self.sphere = torch.cat([cen, rad[:, None]], 1).contiguous()
+        cl = tri_s.reshape(nfp // self.CL, self.CL * 3, 3)
+        self.cbox = torch.cat([cl.min(1)[0], cl.max(1)[0]], 1).contiguous()
+        # (y,z) grid: cell index = clamp(floor((c - c0) / cell), 0, G-1) -- the SAME fp32 expression as the kernel, so the
+        # monotone map sends every point of a triangle's (y,z) bounding box into the triangle's cell range
+        G = int(grid)
+        y0, z0 = float(lo[1]), float(lo[2])
+        cell_y = float((hi[1] - lo[1]) / G) or 1e-6
+        cell_z = float((hi[2] - lo[2]) / G) or 1e-6
+        f32 = torch.float32
+
+        def cell(c, c0, size):
+            return torch.floor((c - torch.tensor(c0, dtype=f32, device=dev)) / torch.tensor(size, dtype=f32, device=dev)).long().clamp(0, G - 1)
+
+        ylo, yhi = cell(tri[..., 1].min(1)[0], y0, cell_y), cell(tri[..., 1].max(1)[0], y0, cell_y)
+        zlo, zhi = cell(tri[..., 2].min(1)[0], z0, cell_z), cell(tri[..., 2].max(1)[0], z0, cell_z)
+        ar = torch.arange(G, device=dev)
+        in_y = (ar[:, None] >= ylo[None]) & (ar[:, None] <= yhi[None])  # (G, NF)
+        in_z = (ar[:, None] >= zlo[None]) & (ar[:, None] <= zhi[None])
+        overlap = (in_y[:, None, :] & in_z[None, :, :]).reshape(G * G, nf)  # cell = cy * G + cz
+        pairs = overlap.nonzero()
+        counts = overlap.sum(1)
+        self.cell_start = torch.cat([torch.zeros(1, dtype=torch.long, device=dev), counts.cumsum(0)]).to(torch.int32).contiguous()
+        self.cell_tri = pairs[:, 1].to(torch.int32).contiguous()
+        if self.cell_tri.numel() == 0:
+            self.cell_tri = torch.zeros(1, dtype=torch.int32, device=dev)
+        c = VanerfMeshAccel()
+        c.tri, c.sphere, c.orig, c.cbox = _ptr(self.tri, f32), _ptr(self.sphere, f32), _ptr(self.orig, torch.int32), _ptr(self.cbox, f32)
+        c.nfp, c.nc = nfp, nfp // self.CL
+        c.cell_start, c.cell_tri = _ptr(self.cell_start, torch.int32), _ptr(self.cell_tri, torch.int32)
+        c.G, c.y0, c.z0, c.cell_y, c.cell_z = G, y0, z0, cell_y, cell_z
+        self.c = c
+
+
 class FrameData:
     """Everything the per-sample kernel needs about one source frame, resident in HBM (struct VanerfFrame)."""
 
@@ -175,6 +239,7 @@ class FrameData:
         self.faces = faces[0].to(torch.int32).contiguous()
         self.verts3 = verts[0].contiguous()
         self.vert_vis = vertex_visibility(self.vert_xy01, self.vert_z01, self.faces)
+        self.accel = MeshAccel(self.verts3, self.faces)
         vis = self.vert_vis[None, :, None]
         # per-vertex features, pre-multiplied by visibility (KNN_vis, src/networks.py:29-32)
         img = img.to(f32)
@@ -238,6 +303,18 @@ def mesh_query(verts3, faces_i32, vert_vis, pts, want_face=False):
     face = torch.empty(n, dtype=torch.int32, device=pts.device) if want_face else None
     check(lib.vanerf_mesh_query(_ptr(verts3, torch.float32), verts3.shape[0], _ptr(faces_i32, torch.int32), faces_i32.shape[0],
                                 _ptr(vert_vis, torch.float32), _ptr(pts, torch.float32), n, _ptr(sdf), _ptr(vis), _ptr(face), _stream()))
+    return (sdf, vis, face) if want_face else (sdf, vis)
+
+
+def mesh_query_accel(accel, verts3, faces_i32, vert_vis, pts, want_face=False):
+    """Same results as mesh_query, through the per-frame acceleration structure."""
+    n = pts.shape[0]
+    sdf = torch.empty(n, dtype=torch.float32, device=pts.device)
+    vis = torch.empty(n, dtype=torch.uint8, device=pts.device)
+    face = torch.empty(n, dtype=torch.int32, device=pts.device) if want_face else None
+    check(lib.vanerf_mesh_query_accel(byref(accel.c), _ptr(verts3, torch.float32), verts3.shape[0], _ptr(faces_i32, torch.int32),
+                                      faces_i32.shape[0], _ptr(vert_vis, torch.float32), _ptr(pts, torch.float32), n, _ptr(sdf), _ptr(vis),
+                                      _ptr(face), _stream()))
     return (sdf, vis, face) if want_face else (sdf, vis)
 
 
@@ -331,7 +408,7 @@ def render_pass(weights, frame, cam_tar, bounds, x0, y0, step, nx, ny, sample_pe
     def march(z):
         S = z.shape[1]
         pts = sample_points(rays["rays_d"], rays["cam_pos"], z)
-        q_sdf, q_vis = mesh_query(frame.verts3, frame.faces, frame.vert_vis, pts)
+        q_sdf, q_vis = mesh_query_accel(frame.accel, frame.verts3, frame.faces, frame.vert_vis, pts)
         noise = None
         if noise_std > 0.0:  # th.randn_like(rad) * rand_noise_std (src/model.py:1155-1156), drawn on the device
             noise = torch.randn(pts.shape[0], device=pts.device, generator=generator) * noise_std
