@@ -75,7 +75,7 @@ def main():
     ap.add_argument("--height", type=int, default=512)
     ap.add_argument("--width", type=int, default=334)
     ap.add_argument("--samples", type=int, default=64)
-    ap.add_argument("--cpu-rays-side", type=int, default=40, help="cpu_baseline sample: side of the strided ray grid (0 = skip)")
+    ap.add_argument("--cpu-rays-side", type=int, default=64, help="cpu_baseline sample: side of the strided ray grid (0 = skip)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -141,8 +141,10 @@ def main():
         "metric": "rendered rays/sec (64 samples/ray) + PSNR vs ref, 512x334 view", "value": rays_total * args.steps / dt, "unit": "rays/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"configs/vanerf.json eval view {H}x{W}, {S} coarse + {S} importance samples/ray (192 network evaluations/ray), "
+        "config": {"workload": f"configs/vanerf.json eval view {H}x{W}, {S} coarse + {S} importance samples/ray, "
                                "two-hand mesh 1558 verts / 3108 faces, 1 source view 256x256, random trained-like weights",
+                   "network_evaluations_per_ray": {"reference": 3 * S, "executed": 2 * S,
+                                                   "note": "fine composite re-uses the coarse evaluations (bit-identical, tests/test_hip_parity.py)"},
                    "rays": rays_total, "parallelism": f"rays{world}" if world > 1 else "single"},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
                      "traffic": None, "kernel": "query_kernel (v_mfma_f32_32x32x2_f32)", "launches": len(events),

@@ -160,6 +160,13 @@ int vanerf_query_samples(const VanerfWeights* w, const VanerfFrame* frame, const
 int vanerf_composite(const float* rgba, const float* z, const float* mesh_sdf, int R, int S, float beta,
                      float* color, float* depth, float* alpha, float* sdf, float* contrib, void* stream);
 
+/* a16 + a18  Fine composite that re-uses the coarse evaluations: sample i of ray r is coarse sample src[r][i] (>= 0) or
+ *     importance sample ~src[r][i] (< 0), in the merged depth order z_fine[R][Sc+Sn] produced by vanerf_importance_merge.
+ *     Identical bits to vanerf_composite on a re-evaluated (R, Sc+Sn) batch (the networks are per-sample pure functions). */
+int vanerf_composite_merged(const float* rgba_c, const float* mesh_sdf_c, int Sc, const float* rgba_n, const float* mesh_sdf_n,
+                            int Sn, const int32_t* src, const float* z_fine, int R, float beta, float* color, float* depth,
+                            float* alpha, float* sdf, float* contrib, void* stream);
+
 /* a17  importance_sample + sort-merge (src/model.py:1424-1462, 1301-1307):
  *     contrib[R][Sc], z[R][Sc], u[R][Sf] (random draws) or NULL with t_lin[Sf] = th.linspace(0, 1, Sf) (uniform=True) ->
  *     z_new[R][Sf], z_fine[R][Sc+Sf] (sorted), src[R][Sc+Sf] int32 (>= 0: coarse sample id, < 0: ~(new sample id)),

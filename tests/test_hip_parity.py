@@ -294,6 +294,10 @@ def test_full_view_properties(R, sd_full):
     # determinism / idempotence: a second launch gives identical bits
     again = R.render_pass(w, fdat, frame["cam_tar"], frame["bounds"], 0, 0, 1, 334, 512, 64, 64)
     assert torch.equal(full["color_fine"], again["color_fine"])
+    # re-using the coarse evaluations in the fine composite gives the same bits as evaluating all 128 samples again
+    redo = R.render_pass(w, fdat, frame["cam_tar"], frame["bounds"], 0, 200, 1, 334, 32, 64, 64, reuse_coarse=False)
+    for k in ("color_fine", "depth_fine", "alpha_fine", "sdf"):
+        assert torch.equal(redo[k], full[k].view(512, 334, -1)[200:232].reshape(redo[k].shape)), k
     # ray independence: rendering rows [100, 164) alone gives the same bits as the full view's rows
     part = R.render_pass(w, fdat, frame["cam_tar"], frame["bounds"], 0, 100, 1, 334, 64, 64, 64)
     assert torch.equal(part["color_fine"], full["color_fine"].view(512, 334, 3)[100:164].reshape(-1, 3))

@@ -24,8 +24,8 @@ cmp(gc, ref["tex_fg"][0], "gpu vs oracle(box) coarse")
 # sample-level: coarse points / sdf / vis / knn
 pc = out["coarse"]["pts"].cpu(); cmp(pc, ref["coarse"]["pts"][0], "coarse pts")
 print("coarse pts bit-equal frac", (pc==ref["coarse"]["pts"][0]).all(-1).float().mean().item())
-print("q_vis mismatch", (out["coarse"]["q_vis"].cpu().bool()!=ref["coarse"]["q_vis"][0,:,0]).sum().item(), "sdf sign mismatch", ((out["coarse"]["q_sdf"].cpu()<0)!=(ref["coarse"]["q_sdf"].view(-1)<0)).sum().item())
-cmp(out["coarse"]["q_sdf"].cpu(), ref["coarse"]["q_sdf"].view(-1), "coarse sdf")
-e=(out["coarse"]["rgba"].cpu()-ref["coarse"]["rgba"].view(-1,5)).abs()
+print("q_vis mismatch", (out["coarse"]["q_vis"].cpu().bool()!=ref["coarse"]["q_vis"][0,:,0]).sum().item(), "sdf sign mismatch", ((out["coarse"]["q_sdf"].cpu().view(-1)<0)!=(ref["coarse"]["q_sdf"].view(-1)<0)).sum().item())
+cmp(out["coarse"]["q_sdf"].cpu().view(-1), ref["coarse"]["q_sdf"].view(-1), "coarse sdf")
+e=(out["coarse"]["rgba"].cpu().view(-1,5)-ref["coarse"]["rgba"].view(-1,5)).abs()
 print("coarse rgba: n samples >1e-4:", int((e.max(1)[0]>1e-4).sum()), "of", e.shape[0], "max", e.max().item())
 zf=out["z_fine"].cpu(); cmp(zf, ref["z_fine"][0], "z_fine")

@@ -64,6 +64,7 @@ _SIGS = {
     "vanerf_knn1": (c_int, [_FP, c_int, _FP, c_int64, _FP, c_void_p]),
     "vanerf_query_samples": (c_int, [c_void_p, POINTER(VanerfFrame), _FP, _FP, _FP, _FP, c_int64, _FP, _FP, _FP, c_void_p]),
     "vanerf_composite": (c_int, [_FP, _FP, _FP, c_int, c_int, c_float, _FP, _FP, _FP, _FP, _FP, c_void_p]),
+    "vanerf_composite_merged": (c_int, [_FP, _FP, c_int, _FP, _FP, c_int, _FP, _FP, c_int, c_float, _FP, _FP, _FP, _FP, _FP, c_void_p]),
     "vanerf_importance_merge": (c_int, [_FP, _FP, _FP, _FP, c_int, c_int, c_int, _FP, _FP, _FP, _FP, c_void_p]),
 }
 EXPORTS = tuple(_SIGS)

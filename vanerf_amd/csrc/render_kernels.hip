@@ -123,32 +123,48 @@ __global__ void sample_points_kernel(const float* __restrict__ rays_d, const flo
 
 // sdf_activation + rgba2out.  Sums are accumulated in fp64 from fp32 products so the result does not
 // depend on the summation order (the reference's float .sum() order is an implementation detail).
+// With `src` the S samples of a ray are gathered from two per-ray tables (the coarse samples and the newly drawn
+// importance samples) in merged depth order: src >= 0 -> table A entry src, src < 0 -> table B entry ~src.  The
+// per-sample networks are pure functions of the sample position, so re-using the coarse evaluations in the fine
+// composite gives the same bits as evaluating them again (the reference re-evaluates them, src/model.py:1305-1345).
 __global__ void composite_kernel(const float* __restrict__ rgba, const float* __restrict__ z, const float* __restrict__ msdf,
-                                 int R, int S, float beta, float* __restrict__ color, float* __restrict__ depth,
+                                 const float* __restrict__ rgba_b, const float* __restrict__ msdf_b, const int32_t* __restrict__ src,
+                                 int Sa, int Sb, int R, int S, float beta, float* __restrict__ color, float* __restrict__ depth,
                                  float* __restrict__ alpha, float* __restrict__ sdf, float* __restrict__ contrib)
 {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= R) return;
-    const float* q = rgba + (size_t)r * S * 5;
+    const float* qa = rgba + (size_t)r * Sa * 5;
+    const float* ma = msdf + (size_t)r * Sa;
+    const float* qb = rgba_b ? rgba_b + (size_t)r * Sb * 5 : nullptr;
+    const float* mb = msdf_b ? msdf_b + (size_t)r * Sb : nullptr;
+    const int32_t* sr = src ? src + (size_t)r * S : nullptr;
     const float* zr = z + (size_t)r * S;
-    const float* ms = msdf + (size_t)r * S;
     double cr = 0, cg = 0, cb = 0, ca = 0, cs = 0, cd = 0;
     float T = 1.0f;
     float zi = zr[0];
     for (int i = 0; i < S; ++i) {
         const float zn = i + 1 < S ? zr[i + 1] : 0.0f;
         const float dist = i + 1 < S ? zn - zi : 1e10f;
-        const float a = q[5 * i] + ms[i];
+        const float* q;
+        float m;
+        if (sr) {
+            const int k = sr[i];
+            if (k >= 0) { q = qa + 5 * k; m = ma[k]; } else { q = qb + 5 * (~k); m = mb[~k]; }
+        } else {
+            q = qa + 5 * i; m = ma[i];
+        }
+        const float a = q[0] + m;
         const float sg = (1.0f / (1.0f + expf(-(-a / beta)))) / beta; // sigmoid(-a / beta) / beta
         const float c = 1.0f - expf(-sg * dist);
         const float w = c * T;
         T = T * (1.0f - c);
         if (contrib) contrib[(size_t)r * S + i] = w;
-        cr += (double)(q[5 * i + 2] * w);
-        cg += (double)(q[5 * i + 3] * w);
-        cb += (double)(q[5 * i + 4] * w);
+        cr += (double)(q[2] * w);
+        cg += (double)(q[3] * w);
+        cb += (double)(q[4] * w);
         ca += (double)w;
-        cs += (double)(q[5 * i + 1] * w);
+        cs += (double)(q[1] * w);
         cd += (double)(zi * w);
         zi = zn;
     }
@@ -277,17 +293,36 @@ extern "C" int vanerf_sample_points(const float* rays_d, const float* cam_pos, c
     });
 }
 
+static void launch_composite(const float* rgba, const float* z, const float* msdf, const float* rgba_b, const float* msdf_b,
+                             const int32_t* src, int Sa, int Sb, int R, int S, float beta, float* color, float* depth, float* alpha,
+                             float* sdf, float* contrib, void* stream)
+{
+    if (R <= 0 || S <= 0) throw_error("vanerf_composite: R=%d S=%d", R, S);
+    if (!(beta > 0.0f)) throw_error("vanerf_composite: beta must be positive");
+    if (beta < 2e-3f) beta = 2e-3f; // sdf_activation clamp (src/model.py:880)
+    hipLaunchKernelGGL(composite_kernel, dim3((R + 63) / 64), dim3(64), 0, (hipStream_t)stream, rgba, z, msdf, rgba_b, msdf_b, src, Sa, Sb,
+                       R, S, beta, color, depth, alpha, sdf, contrib);
+    HIP_CHECK(hipGetLastError());
+}
+
 extern "C" int vanerf_composite(const float* rgba, const float* z, const float* mesh_sdf, int R, int S, float beta,
                                 float* color, float* depth, float* alpha, float* sdf, float* contrib, void* stream)
 {
     return guarded([&] {
         if (!rgba || !z || !mesh_sdf || !color || !depth || !alpha || !sdf) throw_error("vanerf_composite: null argument");
-        if (R <= 0 || S <= 0) throw_error("vanerf_composite: R=%d S=%d", R, S);
-        if (!(beta > 0.0f)) throw_error("vanerf_composite: beta must be positive");
-        if (beta < 2e-3f) beta = 2e-3f; // sdf_activation clamp (src/model.py:880)
-        hipLaunchKernelGGL(composite_kernel, dim3((R + 63) / 64), dim3(64), 0, (hipStream_t)stream, rgba, z, mesh_sdf, R, S, beta,
-                           color, depth, alpha, sdf, contrib);
-        HIP_CHECK(hipGetLastError());
+        launch_composite(rgba, z, mesh_sdf, nullptr, nullptr, nullptr, S, 0, R, S, beta, color, depth, alpha, sdf, contrib, stream);
+    });
+}
+
+extern "C" int vanerf_composite_merged(const float* rgba_c, const float* mesh_sdf_c, int Sc, const float* rgba_n, const float* mesh_sdf_n,
+                                       int Sn, const int32_t* src, const float* z_fine, int R, float beta, float* color, float* depth,
+                                       float* alpha, float* sdf, float* contrib, void* stream)
+{
+    return guarded([&] {
+        if (!rgba_c || !mesh_sdf_c || !rgba_n || !mesh_sdf_n || !src || !z_fine || !color || !depth || !alpha || !sdf)
+            throw_error("vanerf_composite_merged: null argument");
+        if (Sc <= 0 || Sn <= 0) throw_error("vanerf_composite_merged: Sc=%d Sn=%d", Sc, Sn);
+        launch_composite(rgba_c, z_fine, mesh_sdf_c, rgba_n, mesh_sdf_n, src, Sc, Sn, R, Sc + Sn, beta, color, depth, alpha, sdf, contrib, stream);
     });
 }
 

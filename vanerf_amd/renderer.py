@@ -352,6 +352,21 @@ def composite(rgba, z, mesh_sdf, beta, want_contrib=True):
     return color, depth, alpha, contrib, sdf
 
 
+def composite_merged(rgba_c, sdf_c, rgba_n, sdf_n, src, z_fine, beta, want_contrib=False):
+    """Fine composite over [coarse samples | new importance samples] in merged depth order (vanerf_composite_merged)."""
+    R, S = z_fine.shape
+    Sc, Sn = sdf_c.shape[1], sdf_n.shape[1]
+    assert Sc + Sn == S and src.shape == (R, S)
+    dev = z_fine.device
+    color = torch.empty(R, 3, dtype=torch.float32, device=dev)
+    depth, alpha, sdf = (torch.empty(R, dtype=torch.float32, device=dev) for _ in range(3))
+    contrib = torch.empty(R, S, dtype=torch.float32, device=dev) if want_contrib else None
+    check(lib.vanerf_composite_merged(_ptr(rgba_c, torch.float32), _ptr(sdf_c, torch.float32), Sc, _ptr(rgba_n, torch.float32),
+                                      _ptr(sdf_n, torch.float32), Sn, _ptr(src, torch.int32), _ptr(z_fine, torch.float32), R, float(beta),
+                                      _ptr(color), _ptr(depth), _ptr(alpha), _ptr(sdf), _ptr(contrib), _stream()))
+    return color, depth, alpha, contrib, sdf
+
+
 def importance_merge(contrib, z, sample_per_ray, u=None, want_idx=False):
     """importance_sample + sort-merge (src/model.py:1424-1462, 1301-1307).  contrib, z: (R,Sc) -> z_new (R,Sf), z_fine (R,Sc+Sf), src."""
     R, Sc = z.shape
@@ -399,14 +414,21 @@ def sample_points(rays_d, cam_pos, z):
 # one pass: rays -> coarse march -> importance -> fine march (src/model.py:1102-1360)
 # ------------------------------------------------------------------------------------------------
 def render_pass(weights, frame, cam_tar, bounds, x0, y0, step, nx, ny, sample_per_ray_c=64, sample_per_ray_f=64, fine=True,
-                jitter=None, u=None, noise_std=0.0, generator=None, debug=False, kernel_events=None, y_step=None):
-    """Returns flat per-ray tensors: color/depth/alpha (coarse), color_fine/depth_fine/alpha_fine/sdf (fine), index, z, z_fine."""
+                jitter=None, u=None, noise_std=0.0, generator=None, debug=False, kernel_events=None, y_step=None, reuse_coarse=True):
+    """Returns flat per-ray tensors: color/depth/alpha (coarse), color_fine/depth_fine/alpha_fine/sdf (fine), index, z, z_fine.
+
+    reuse_coarse: the fine composite needs the networks at the Sc coarse and the Sf new depths of every ray.  The reference
+    evaluates all Sc+Sf again (src/model.py:1305-1345); the per-sample networks are pure functions of the position, so by
+    default only the Sf new samples are evaluated and the coarse results are merged in by depth (same bits, 1/3 less work).
+    With per-sample noise (training, rand_noise_std > 0) the reference draws fresh noise for the re-evaluated coarse
+    samples, so re-use is switched off there."""
     Sc, Sf = int(sample_per_ray_c), int(sample_per_ray_f)
     rays = ray_setup(cam_tar, bounds, x0, y0, step, nx, ny, Sc, jitter=jitter, device=frame.verts3.device, y_step=y_step)
     R = nx * ny
+    if noise_std > 0.0:
+        reuse_coarse = False
 
-    def march(z):
-        S = z.shape[1]
+    def evaluate(z):
         pts = sample_points(rays["rays_d"], rays["cam_pos"], z)
         q_sdf, q_vis = mesh_query_accel(frame.accel, frame.verts3, frame.faces, frame.vert_vis, pts)
         noise = None
@@ -419,17 +441,23 @@ def render_pass(weights, frame, cam_tar, bounds, x0, y0, step, nx, ny, sample_pe
         if kernel_events is not None:
             e1.record()
             kernel_events.append((e0, e1, pts.shape[0]))
-        color, depth, alpha, contrib, sdf = composite(rgba.view(R, S, 5), z, q_sdf.view(R, S), weights.beta)
-        return dict(pts=pts, q_sdf=q_sdf, q_vis=q_vis, rgba=rgba, color=color, depth=depth, alpha=alpha, contrib=contrib, sdf=sdf)
+        return dict(pts=pts, q_sdf=q_sdf.view(R, -1), q_vis=q_vis, rgba=rgba.view(R, -1, 5))
 
-    c = march(rays["z"])
+    c = evaluate(rays["z"])
+    c["color"], c["depth"], c["alpha"], c["contrib"], c["sdf"] = composite(c["rgba"], rays["z"], c["q_sdf"], weights.beta)
     out = {"color": c["color"], "depth": c["depth"], "alpha": c["alpha"], "index": rays["index"], "z": rays["z"], "hit": rays["hit"],
            "rays_d": rays["rays_d"], "cam_pos": rays["cam_pos"]}
     if debug:
         out["coarse"] = c
     if fine:
         z_new, z_fine, src = importance_merge(c["contrib"], rays["z"], Sf, u=u)
-        f = march(z_fine)
+        if reuse_coarse:
+            f = evaluate(z_new)
+            f["color"], f["depth"], f["alpha"], f["contrib"], f["sdf"] = composite_merged(c["rgba"], c["q_sdf"], f["rgba"], f["q_sdf"], src,
+                                                                                          z_fine, weights.beta, want_contrib=debug)
+        else:
+            f = evaluate(z_fine)
+            f["color"], f["depth"], f["alpha"], f["contrib"], f["sdf"] = composite(f["rgba"], z_fine, f["q_sdf"], weights.beta, want_contrib=debug)
         out.update({"color_fine": f["color"], "depth_fine": f["depth"], "alpha_fine": f["alpha"], "sdf": f["sdf"], "z_fine": z_fine})
         if debug:
             out["fine"] = f
