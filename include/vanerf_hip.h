@@ -140,20 +140,26 @@ typedef struct {
     const int32_t* cell_tri;   /* original face ids per cell */
     int G;
     float y0, z0, cell_y, cell_z;
+    const float* vsort;        /* [nvc*16][4] Morton-sorted vertices (xyz, original index as int bits), padded with far points */
+    const float* vbox;         /* [nvc][6]    AABB of each cluster of 16 vertices */
+    int nvc;
 } VanerfMeshAccel;
 
+/* knn_idx (may be NULL): 1-NN vertex of every point (knn_points K=1, src/networks.py:28), found in the same pass. */
 int vanerf_mesh_query_accel(const VanerfMeshAccel* accel, const float* verts, int nv, const int32_t* faces, int nf,
-                            const float* vert_vis, const float* pts, int64_t n, float* sdf, uint8_t* vis, int32_t* face, void* stream);
+                            const float* vert_vis, const float* pts, int64_t n, float* sdf, uint8_t* vis, int32_t* face,
+                            int32_t* knn_idx, void* stream);
 
 /* a10 knn_points K=1 (src/networks.py:28): verts[NV][4], pts[N][3] -> idx[N] int32 (first minimum). */
 int vanerf_knn1(const float* verts4, int nv, const float* pts, int64_t n, int32_t* idx, void* stream);
 
 /* a7-a15  VANeRF.query + eval_func for N samples (src/model.py:748-957, 1140-1160), n_views = 1:
- *     pts[N][3], query_sdf[N], query_vis[N] (u8), noise[N] or NULL (rand_noise_std draws, model.py:1156)
- *     -> out[N][5] = [alpha, sdf, r, g, b];  valid[N] (u8, may be NULL);  knn_idx[N] (int32, may be NULL)                */
+ *     pts[N][3], query_sdf[N], query_vis[N] (u8), knn_idx[N] (1-NN vertex, from vanerf_mesh_query_accel or vanerf_knn1),
+ *     noise[N] or NULL (rand_noise_std draws, model.py:1156)
+ *     -> out[N][5] = [alpha, sdf, r, g, b];  valid[N] (u8, may be NULL)                                                  */
 int vanerf_query_samples(const VanerfWeights* w, const VanerfFrame* frame, const float* pts, const float* query_sdf,
-                         const uint8_t* query_vis, const float* noise, int64_t n, float* out, uint8_t* valid,
-                         int32_t* knn_idx, void* stream);
+                         const uint8_t* query_vis, const int32_t* knn_idx, const float* noise, int64_t n, float* out,
+                         uint8_t* valid, void* stream);
 
 /* a16  sdf_activation + rgba2out (src/model.py:879-882, 1464-1494):
  *     rgba[R][S][5], z[R][S], mesh_sdf[R][S] -> color[R][3], depth[R], alpha[R], sdf[R], contrib[R][S] (may be NULL)      */

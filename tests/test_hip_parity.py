@@ -109,8 +109,10 @@ def test_mesh_query_accel_equals_brute_force(R):
         vv = dev((torch.rand(verts.shape[0], generator=g) > 0.5).float())
         accel = R.MeshAccel(verts, faces)
         s0, v0, f0 = R.mesh_query(verts, faces, vv, p, want_face=True)
-        s1, v1, f1 = R.mesh_query_accel(accel, verts, faces, vv, p, want_face=True)
+        s1, v1, f1, k1 = R.mesh_query_accel(accel, verts, faces, vv, p, want_face=True)
         assert torch.equal(s0, s1) and torch.equal(v0, v1) and torch.equal(f0, f1)
+        v4 = torch.cat([verts, torch.zeros(verts.shape[0], 1, device="cuda")], 1).contiguous()
+        assert torch.equal(k1, R.knn1(v4, p))  # cluster-pruned 1-NN == exhaustive 1-NN (== oracle, test_knn1_bit_exact)
         assert 0.02 < (s0 < 0).float().mean() < 0.9
 
 
@@ -199,8 +201,9 @@ def _query_both(R, sd, frame, pts, view=None):
     ref = orc.eval_func(sd, rgba, valid, frame["cam_in"]["nml_scale"])[0]
     fdat = _frame_data(R, sd, frame)
     w = R.PackedWeights(sd)
-    got, gvalid, gknn = R.query_samples(w, fdat, dev(pts), dev(q_sdf[0].contiguous()), dev(q_vis[0, :, 0].to(torch.uint8).contiguous()),
-                                        want_valid=True, want_knn=True)
+    gknn = R.mesh_query_accel(fdat.accel, fdat.verts3, fdat.faces, fdat.vert_vis, dev(pts))[-1]
+    got, gvalid = R.query_samples(w, fdat, dev(pts), dev(q_sdf[0].contiguous()), dev(q_vis[0, :, 0].to(torch.uint8).contiguous()), gknn,
+                                  want_valid=True)
     return ref, valid[0, :, 0], got.cpu(), gvalid.cpu().bool(), gknn.cpu().long(), fdat, vert_vis
 
 
@@ -229,8 +232,9 @@ def test_query_samples_vs_reference_golden(R, sd_full, golden):
     fdat = _frame_data(R, sd_full, frame)
     assert (fdat.vfeat_tex.cpu()[:, :29] - g["vert_feat29"][0] * g["vert_vis"][0]).abs().max() <= 1e-4  # MIOpen convs vs CPU, values up to ~3
     w = R.PackedWeights(sd_full)
-    got, gvalid = R.query_samples(w, fdat, dev(g["pts"][0].contiguous()), dev(g["q_sdf"][0].contiguous()),
-                                  dev(g["q_vis"][0, :, 0].to(torch.uint8).contiguous()), want_valid=True)
+    gpts = dev(g["pts"][0].contiguous())
+    got, gvalid = R.query_samples(w, fdat, gpts, dev(g["q_sdf"][0].contiguous()), dev(g["q_vis"][0, :, 0].to(torch.uint8).contiguous()),
+                                  R.knn1(fdat.verts4, gpts), want_valid=True)
     ref = orc.eval_func(sd_full, g["out"], g["valid"], 100.0)[0]
     assert torch.equal(gvalid.cpu().bool(), g["valid"][0, :, 0])
     assert (got.cpu() - ref).abs().max() <= TOL

@@ -46,6 +46,7 @@ class VanerfMeshAccel(Structure):
     _fields_ = [
         ("tri", _FP), ("sphere", _FP), ("orig", _FP), ("cbox", _FP), ("nfp", c_int), ("nc", c_int),
         ("cell_start", _FP), ("cell_tri", _FP), ("G", c_int), ("y0", c_float), ("z0", c_float), ("cell_y", c_float), ("cell_z", c_float),
+        ("vsort", _FP), ("vbox", _FP), ("nvc", c_int),
     ]
 
 
@@ -60,9 +61,9 @@ _SIGS = {
     "vanerf_sample_points": (c_int, [_FP, _FP, _FP, c_int, c_int, _FP, c_void_p]),
     "vanerf_vertex_visibility": (c_int, [_FP, _FP, c_int, _FP, c_int, c_int, _FP, _FP, c_void_p]),
     "vanerf_mesh_query": (c_int, [_FP, c_int, _FP, c_int, _FP, _FP, c_int64, _FP, _FP, _FP, c_void_p]),
-    "vanerf_mesh_query_accel": (c_int, [POINTER(VanerfMeshAccel), _FP, c_int, _FP, c_int, _FP, _FP, c_int64, _FP, _FP, _FP, c_void_p]),
+    "vanerf_mesh_query_accel": (c_int, [POINTER(VanerfMeshAccel), _FP, c_int, _FP, c_int, _FP, _FP, c_int64, _FP, _FP, _FP, _FP, c_void_p]),
     "vanerf_knn1": (c_int, [_FP, c_int, _FP, c_int64, _FP, c_void_p]),
-    "vanerf_query_samples": (c_int, [c_void_p, POINTER(VanerfFrame), _FP, _FP, _FP, _FP, c_int64, _FP, _FP, _FP, c_void_p]),
+    "vanerf_query_samples": (c_int, [c_void_p, POINTER(VanerfFrame), _FP, _FP, _FP, _FP, _FP, c_int64, _FP, _FP, c_void_p]),
     "vanerf_composite": (c_int, [_FP, _FP, _FP, c_int, c_int, c_float, _FP, _FP, _FP, _FP, _FP, c_void_p]),
     "vanerf_composite_merged": (c_int, [_FP, _FP, c_int, _FP, _FP, c_int, _FP, _FP, c_int, c_float, _FP, _FP, _FP, _FP, _FP, c_void_p]),
     "vanerf_importance_merge": (c_int, [_FP, _FP, _FP, _FP, c_int, c_int, c_int, _FP, _FP, _FP, _FP, c_void_p]),

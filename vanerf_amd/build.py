@@ -20,6 +20,7 @@ def _stale():
 
 
 def build(force=False, verbose=False, extra=()):
+    extra = tuple(extra) + tuple(os.environ.get("VANERF_HIPCC_FLAGS", "").split())
     if not force and not _stale():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

@@ -230,7 +230,8 @@ __global__ __launch_bounds__(256) void knn1_kernel(const float4* __restrict__ ve
 // The structure is built per source frame by vanerf_amd/renderer.py:MeshAccel (torch on the device).
 constexpr int CL = 16; // triangles per cluster
 constexpr int MA_BLOCK = 256;
-constexpr int MA_MAX_CLUSTERS = 1024;
+constexpr int MA_MAX_CLUSTERS = 4096;
+constexpr int MA_MAX_VCLUSTERS = 1024;
 
 __device__ __forceinline__ float box_dist2(f3 p, const float* b)
 {
@@ -243,46 +244,68 @@ __device__ __forceinline__ float box_dist2(f3 p, const float* b)
 __global__ __launch_bounds__(MA_BLOCK) void mesh_query_accel_kernel(const VanerfMeshAccel A, const float* __restrict__ V,
                                                                     const int32_t* __restrict__ F, const float* __restrict__ vert_vis,
                                                                     const float* __restrict__ P, long long n, float* __restrict__ sdf,
-                                                                    uint8_t* __restrict__ vis, int32_t* __restrict__ face)
+                                                                    uint8_t* __restrict__ vis, int32_t* __restrict__ face,
+                                                                    int32_t* __restrict__ knn)
 {
-    __shared__ float s_box[MA_MAX_CLUSTERS * 6];
+    // dynamic LDS: [nc][6] triangle-cluster boxes | [nvc][6] vertex-cluster boxes | [nvc*16] sorted vertices (float4)
+    extern __shared__ float4 s_dyn[];
+    float4* s_vs = s_dyn;
+    float* s_vbox = reinterpret_cast<float*>(s_vs + A.nvc * CL);
+    float* s_box = s_vbox + A.nvc * 6;
     for (int k = threadIdx.x; k < A.nc * 6; k += MA_BLOCK) s_box[k] = A.cbox[k];
+    for (int k = threadIdx.x; k < A.nvc * 6; k += MA_BLOCK) s_vbox[k] = A.vbox[k];
+    for (int k = threadIdx.x; k < A.nvc * CL; k += MA_BLOCK) s_vs[k] = reinterpret_cast<const float4*>(A.vsort)[k];
     __syncthreads();
     for (long long i = (long long)blockIdx.x * MA_BLOCK + threadIdx.x; i < n; i += (long long)gridDim.x * MA_BLOCK) {
         const f3 p = {P[3 * i], P[3 * i + 1], P[3 * i + 2]};
+        // ---- 1-NN vertex (knn_points K=1, src/networks.py:28): clusters of 16 Morton-sorted vertices; squared distance
+        //      ((dx*dx + dy*dy) + dz*dz), first minimum in ORIGINAL vertex order (oracle/mesh_oracle.c:knn1)
+        float vb = INFINITY;
+        int vi = 0x7fffffff;
+        {
+            auto eval_v = [&](int c) {
+                for (int k = 0; k < CL; ++k) {
+                    const float4 v = s_vs[c * CL + k];
+                    const float dx = p.x - v.x, dy = p.y - v.y, dz = p.z - v.z;
+                    const float d = (dx * dx + dy * dy) + dz * dz;
+                    const int oi = __float_as_int(v.w);
+                    if (d < vb || (d == vb && oi < vi)) { vb = d; vi = oi; }
+                }
+            };
+            float vmin = INFINITY;
+            int cm = 0;
+            for (int c = 0; c < A.nvc; ++c) {
+                const float lb = box_dist2(p, s_vbox + 6 * c);
+                if (lb < vmin) { vmin = lb; cm = c; }
+            }
+            eval_v(cm);
+            for (int c = 0; c < A.nvc; ++c) {
+                if (c == cm) continue;
+                if (box_dist2(p, s_vbox + 6 * c) > vb * (1.0f + 1e-4f) + 1e-12f) continue;
+                eval_v(c);
+            }
+            if (knn) knn[i] = vi;
+        }
+        // ---- closest face: the nearest vertex belongs to some triangle, so its distance bounds the closest-face distance
+        //      from above; a cluster / triangle whose lower bound exceeds min(best, that bound) by the safety margin cannot
+        //      hold the minimum or a tie.
         float best = INFINITY;
         int bf = 0x7fffffff;
-        auto eval_cluster = [&](int c, bool filter) {
-            const float bound = best * (1.0f + 1e-4f) + 1e-12f;
+        for (int c = 0; c < A.nc; ++c) {
+            const float cap = fminf(best, vb) * (1.0f + 1e-4f) + 1e-12f;
+            if (box_dist2(p, s_box + 6 * c) > cap) continue;
             for (int k = 0; k < CL; ++k) {
                 const int t = c * CL + k;
-                if (filter) {
-                    const float4 sp = reinterpret_cast<const float4*>(A.sphere)[t];
-                    const float ex = p.x - sp.x, ey = p.y - sp.y, ez = p.z - sp.z;
-                    const float g = fmaxf(sqrtf((ex * ex + ey * ey) + ez * ez) - sp.w, 0.0f);
-                    if (g * g > bound) continue;
-                }
+                const float4 sp = reinterpret_cast<const float4*>(A.sphere)[t];
+                const float ex = p.x - sp.x, ey = p.y - sp.y, ez = p.z - sp.z;
+                const float g = fmaxf(sqrtf((ex * ex + ey * ey) + ez * ez) - sp.w, 0.0f);
+                if (g * g > fminf(best, vb) * (1.0f + 1e-4f) + 1e-12f) continue;
                 const float* q = A.tri + (size_t)t * 9;
                 const f3 a = {q[0], q[1], q[2]}, b = {q[3], q[4], q[5]}, c3 = {q[6], q[7], q[8]};
                 const float d = point_tri_dist2(p, a, b, c3);
                 const int of = A.orig[t];
                 if (d < best || (d == best && of < bf)) { best = d; bf = of; }
             }
-        };
-        // pass 1: the cluster with the smallest lower bound seeds `best`
-        float lmin = INFINITY;
-        int cmin = 0;
-        for (int c = 0; c < A.nc; ++c) {
-            const float lb = box_dist2(p, s_box + 6 * c);
-            if (lb < lmin) { lmin = lb; cmin = c; }
-        }
-        eval_cluster(cmin, false);
-        // pass 2: every cluster that can still hold the minimum (or a tie)
-        for (int c = 0; c < A.nc; ++c) {
-            if (c == cmin) continue;
-            const float lb = box_dist2(p, s_box + 6 * c);
-            if (lb > best * (1.0f + 1e-4f) + 1e-12f) continue;
-            eval_cluster(c, true);
         }
         // inside test on the (y,z) grid
         int cnt = 0;
@@ -376,7 +399,7 @@ extern "C" int vanerf_knn1(const float* verts4, int nv, const float* pts, int64_
 
 extern "C" int vanerf_mesh_query_accel(const VanerfMeshAccel* accel, const float* verts, int nv, const int32_t* faces, int nf,
                                        const float* vert_vis, const float* pts, int64_t n, float* sdf, uint8_t* vis, int32_t* face,
-                                       void* stream)
+                                       int32_t* knn_idx, void* stream)
 {
     return guarded([&] {
         if (!accel || !verts || !faces || !vert_vis || !pts || !sdf || !vis) throw_error("vanerf_mesh_query_accel: null argument");
@@ -385,11 +408,15 @@ extern "C" int vanerf_mesh_query_accel(const VanerfMeshAccel* accel, const float
         if (A.nc <= 0 || A.nc > MA_MAX_CLUSTERS || A.nfp != A.nc * CL || A.nfp < nf) throw_error("vanerf_mesh_query_accel: bad cluster table (nc=%d nfp=%d nf=%d)", A.nc, A.nfp, nf);
         if (A.G <= 0 || !(A.cell_y > 0.0f) || !(A.cell_z > 0.0f)) throw_error("vanerf_mesh_query_accel: bad grid");
         if (nv <= 0 || nf <= 0 || n < 0) throw_error("vanerf_mesh_query_accel: nv=%d nf=%d n=%lld", nv, nf, (long long)n);
+        if (!A.vsort || !A.vbox || A.nvc <= 0 || A.nvc > MA_MAX_VCLUSTERS || A.nvc * CL < nv)
+            throw_error("vanerf_mesh_query_accel: bad vertex cluster table (nvc=%d nv=%d)", A.nvc, nv);
+        const size_t lds = sizeof(float) * ((size_t)A.nvc * CL * 4 + (size_t)A.nvc * 6 + (size_t)A.nc * 6);
+        if (lds > 64 * 1024) throw_error("vanerf_mesh_query_accel: mesh too large for the LDS-resident tables (%zu bytes)", lds);
         if (n == 0) return;
         long long blocks = (n + MA_BLOCK - 1) / MA_BLOCK;
         if (blocks > 256 * 8) blocks = 256 * 8;
-        hipLaunchKernelGGL(mesh_query_accel_kernel, dim3((unsigned)blocks), dim3(MA_BLOCK), 0, (hipStream_t)stream, A, verts, faces, vert_vis,
-                           pts, (long long)n, sdf, vis, face);
+        hipLaunchKernelGGL(mesh_query_accel_kernel, dim3((unsigned)blocks), dim3(MA_BLOCK), lds, (hipStream_t)stream, A, verts, faces, vert_vis,
+                           pts, (long long)n, sdf, vis, face, knn_idx);
         HIP_CHECK(hipGetLastError());
     });
 }

@@ -6,11 +6,13 @@
 // a sample split every K dimension between them (half h = l >> 5), see layer_spec.h.  All 20 dense
 // layers run as v_mfma_f32_32x32x2_f32 chains whose accumulators stay in registers from the
 // bilinear gathers to the final (alpha, sdf, rgb) store: activations never touch LDS or HBM.
-// LDS holds only the mesh vertices (1-NN search) and the key points (positional encoding).
+// LDS holds only the key points (positional encoding); the 1-NN vertex index arrives from vanerf_mesh_query_accel.
 // Weights stream from L2 as pre-permuted MFMA A-fragments (weights_pack.cpp).
 //
 // Built with -ffp-contract=off: the integer-valued outputs (1-NN index) depend on fp32 compare
 // results and must match oracle/mesh_oracle.c bit for bit; fused multiply-adds are spelled fmaf().
+#include <utility>
+
 #include "common.h"
 
 using namespace vanerf;
@@ -22,6 +24,23 @@ namespace {
 constexpr int WAVES_PER_BLOCK = 4;
 constexpr int BLOCK = 64 * WAVES_PER_BLOCK;
 
+// Diagnostic build only (-DVANERF_STAMPS): per-phase s_memtime deltas summed per wave into QueryParams::stamps.
+// No stamp executes in the product build; stamp values never reach an output element.
+#ifdef VANERF_STAMPS
+#define STAMP(k)                                                                                  \
+    do {                                                                                          \
+        unsigned long long t_;                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");               \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+        phase_cycles[k] += t_ - t_prev;                                                           \
+        t_prev = t_;                                                                              \
+    } while (0)
+constexpr int N_PHASES = 12;
+#else
+#define STAMP(k) do { } while (0)
+#endif
+
 struct QueryParams {
     VanerfFrame f;
     const float* w;
@@ -30,17 +49,20 @@ struct QueryParams {
     const float* qsdf;
     const uint8_t* qvis;
     const float* noise;
+    const int32_t* knn_in;
     long long n;
     float* out;
     uint8_t* valid;
-    int32_t* knn_idx;
+    unsigned long long* stamps; // [waves][N_PHASES] (diagnostic build), else unused
 };
 
 // ---------------------------------------------------------------------------------------------
-// weight fragment stream with a two-deep register prefetch
+// weight fragment stream: register ring, prefetch distance ~1000 cycles
 // ---------------------------------------------------------------------------------------------
 template <int NB> struct WFrag { float v[NB]; };
 
+// Address = wave-uniform base (SGPR pair) + per-lane element offset (one VGPR): `global_load ... v_off, s[base] offset:imm`.
+// A per-lane 64-bit pointer would cost two VGPRs per 4 KB window of the unrolled stream.
 template <int NB> __device__ __forceinline__ WFrag<NB> wload(const float* p);
 template <> __device__ __forceinline__ WFrag<1> wload<1>(const float* p) { return {{p[0]}}; }
 template <> __device__ __forceinline__ WFrag<2> wload<2>(const float* p)
@@ -55,33 +77,20 @@ template <> __device__ __forceinline__ WFrag<4> wload<4>(const float* p)
     return {{t.x, t.y, t.z, t.w}};
 }
 
-// Address = uniform base (SGPR pair, advanced with scalar adds) + per-lane element offset (one VGPR):
-// `global_load ... v_off, s[base] offset:imm`.  A per-lane 64-bit pointer would cost two VGPRs per 4 KB window.
-template <int NB> struct WStream {
-    const float* sb; // wave-uniform
-    unsigned voff;   // lane * NB
-    WFrag<NB> f0, f1;
-    __device__ __forceinline__ WStream(const float* base, int lane)
-    {
-        sb = base;
-        voff = (unsigned)lane * NB;
-        f0 = wload<NB>(sb + voff);
-        f1 = wload<NB>(sb + 64 * NB + voff);
-        sb += 2 * 64 * NB;
-    }
-    __device__ __forceinline__ WFrag<NB> next()
-    {
-        WFrag<NB> r = f0;
-        f0 = f1;
-        f1 = wload<NB>(sb + voff);
-        sb += 64 * NB;
-        return r;
-    }
-};
-
-template <int NB> __device__ __forceinline__ void mma(f32x16 (&acc)[NB], WStream<NB>& s, float b)
+template <class F, int... I> __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>)
 {
-    WFrag<NB> a = s.next();
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F> __device__ __forceinline__ void static_for(F&& f)
+{
+    static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
+}
+
+// ring depth per block count: D * NB = 15..16 VGPRs, D * NB MFMAs (x 64 cycles) between a load and its use
+template <int NB> struct RingDepth { static constexpr int value = NB == 1 ? 16 : NB == 2 ? 8 : NB == 3 ? 5 : 4; };
+
+template <int NB> __device__ __forceinline__ void mfma_step(f32x16 (&acc)[NB], const WFrag<NB>& a, float b)
+{
 #pragma unroll
     for (int ob = 0; ob < NB; ++ob) acc[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[ob], b, acc[ob], 0, 0, 0);
 #ifdef VANERF_PIN_KSTEPS // experiment knob: forbid scheduling across k-steps
@@ -89,11 +98,25 @@ template <int NB> __device__ __forceinline__ void mma(f32x16 (&acc)[NB], WStream
 #endif
 }
 
-// consume registers 0..NREGS-1 of a previous accumulator block as k-pairs
-template <int NB, int NREGS> __device__ __forceinline__ void mma_regs(f32x16 (&acc)[NB], WStream<NB>& s, const f32x16& src)
+// Runs the T k-steps of one layer, fully unrolled.  operand(integral_constant<int, t>) returns the B operand (this
+// lane's activation) of step t; step t's A fragment lives in ring slot t % D and is re-loaded with step t + D as soon
+// as it has been consumed.  `sbase` is the wave-uniform address of step 0, `voff` = lane * NB.
+template <int NB, int T, class Op>
+__device__ __forceinline__ void run_layer(f32x16 (&acc)[NB], const float* sbase, unsigned voff, Op&& operand)
 {
-#pragma unroll
-    for (int r = 0; r < NREGS; ++r) mma<NB>(acc, s, src[r]);
+    constexpr int D = RingDepth<NB>::value;
+    WFrag<NB> ring[D];
+    static_for<D>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        if constexpr (i < T) ring[i] = wload<NB>(sbase + i * 64 * NB + voff);
+    });
+    static_for<T>([&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+        const float b = operand(tc);
+        const WFrag<NB> a = ring[t % D];
+        if constexpr (t + D < T) ring[t % D] = wload<NB>(sbase + (t + D) * 64 * NB + voff);
+        mfma_step<NB>(acc, a, b);
+    });
 }
 
 template <int NB> __device__ __forceinline__ void zero(f32x16 (&acc)[NB])
@@ -109,13 +132,14 @@ template <int NB> __device__ __forceinline__ void zero(f32x16 (&acc)[NB])
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
-// torch.nn.Softplus(beta=100, threshold=20) (src/utils.py:656): x if 100x > 20 else log1p(exp(100x))/100,
-// evaluated as max(x,0) + log(1 + exp(-|100x|))/100 (identical value, |error| < 2e-9).
+// torch.nn.Softplus(beta=100, threshold=20) (src/utils.py:656): x if 100x > 20 else log1p(exp(100x))/100, evaluated as
+// max(x,0) + ln2/100 * log2(1 + exp2(-|100x| * log2(e))) on the raw v_exp_f32 / v_log_f32 (1 + e is in [1,2]: no denormal
+// or range handling needed).  |error| < 1e-8 against fp64 over x in [-0.5, 0.5] (tools/probe_trig.hip).
 __device__ __forceinline__ float softplus100(float x)
 {
-    float t = x * 100.0f;
-    float e = __expf(-fabsf(t));
-    float r = fmaxf(x, 0.0f) + __logf(1.0f + e) * 0.01f;
+    const float t = x * 100.0f;
+    const float e = __builtin_amdgcn_exp2f(-fabsf(t) * 1.44269504f);
+    const float r = fmaxf(x, 0.0f) + __builtin_amdgcn_logf(1.0f + e) * 6.93147181e-3f;
     return t > 20.0f ? x : r;
 }
 
@@ -193,66 +217,47 @@ template <int C4> __device__ __forceinline__ void load_row(const float* row, flo
 }
 
 // one GeoVisFusion scale (src/networks.py:83-94 / 96-104): gates, gated 2-layer MLP.
-//   HC = channels per lane half (32 for the 64-channel map, 4 for the 8-channel map), NBO = output blocks
+//   HC = channels per lane half (32 for the 64-channel map, 4 for the 8-channel map), NBO = output blocks,
+//   NREG_MID = registers of the last hidden block that carry real channels
 template <int HC, int NBO, int NREG_MID>
-__device__ __forceinline__ void geo_scale(const float* w, const LayerOffsets& offs, int l_at_a, int lane, int h,
+__device__ __forceinline__ void geo_scale(const float* W, const LayerOffsets& offs, int l_at_a, int lane,
                                           float (&pix)[HC], float (&nn)[HC], float (&tw)[HC], float s0, float s1,
                                           f32x16 (&outacc)[NBO])
 {
+    constexpr int TIN = 3 * HC + 2;
+    auto input = [&](auto tc) -> float {
+        constexpr int t = decltype(tc)::value;
+        if constexpr (t < HC) return pix[t];
+        else if constexpr (t < 2 * HC) return nn[t - HC];
+        else if constexpr (t < 3 * HC) return tw[t - 2 * HC];
+        else if constexpr (t == 3 * HC) return s0;
+        else return s1;
+    };
     f32x16 at[1];
     zero<1>(at);
-    {
-        WStream<1> s(w + offs.off[l_at_a], lane);
-#pragma unroll
-        for (int t = 0; t < HC; ++t) mma<1>(at, s, pix[t]);
-#pragma unroll
-        for (int t = 0; t < HC; ++t) mma<1>(at, s, nn[t]);
-#pragma unroll
-        for (int t = 0; t < HC; ++t) mma<1>(at, s, tw[t]);
-        mma<1>(at, s, s0);
-        mma<1>(at, s, s1);
-    }
+    run_layer<1, TIN>(at, W + offs.off[l_at_a], (unsigned)lane, input);
     relu<1>(at);
     f32x16 gate[1];
     zero<1>(gate);
-    {
-        WStream<1> s(w + offs.off[l_at_a + 1], lane);
-        mma_regs<1, 6>(gate, s, at[0]);
-    }
+    run_layer<1, 6>(gate, W + offs.off[l_at_a + 1], (unsigned)lane, [&](auto tc) -> float { return at[0][decltype(tc)::value]; });
     // gates live in rows 0..2 = registers 0..2 of the h = 0 lanes
-    float a0 = __shfl(sigmoid_f(gate[0][0]), lane & 31);
-    float a1 = __shfl(sigmoid_f(gate[0][1]), lane & 31);
-    float a2 = __shfl(sigmoid_f(gate[0][2]), lane & 31);
+    const float a0 = __shfl(sigmoid_f(gate[0][0]), lane & 31);
+    const float a1 = __shfl(sigmoid_f(gate[0][1]), lane & 31);
+    const float a2 = __shfl(sigmoid_f(gate[0][2]), lane & 31);
 #pragma unroll
     for (int t = 0; t < HC; ++t) { pix[t] *= a0; nn[t] *= a1; tw[t] *= a2; }
     f32x16 mid[NBO];
     zero<NBO>(mid);
-    {
-        WStream<NBO> s(w + offs.off[l_at_a + 2], lane);
-#pragma unroll
-        for (int t = 0; t < HC; ++t) mma<NBO>(mid, s, pix[t]);
-#pragma unroll
-        for (int t = 0; t < HC; ++t) mma<NBO>(mid, s, nn[t]);
-#pragma unroll
-        for (int t = 0; t < HC; ++t) mma<NBO>(mid, s, tw[t]);
-        mma<NBO>(mid, s, s0);
-        mma<NBO>(mid, s, s1);
-    }
+    run_layer<NBO, TIN>(mid, W + offs.off[l_at_a + 2], (unsigned)lane * NBO, input);
     relu<NBO>(mid);
     zero<NBO>(outacc);
-    {
-        WStream<NBO> s(w + offs.off[l_at_a + 3], lane);
-#pragma unroll
-        for (int ob = 0; ob < NBO; ++ob) mma_regs<NBO, NREG_MID>(outacc, s, mid[ob]);
-    }
-    (void)h;
+    run_layer<NBO, (NBO - 1) * 16 + NREG_MID>(outacc, W + offs.off[l_at_a + 3], (unsigned)lane * NBO,
+                                              [&](auto tc) -> float { constexpr int t = decltype(tc)::value; return mid[t / 16][t % 16]; });
 }
 
 __global__ __launch_bounds__(BLOCK, 2) void query_kernel(const QueryParams P)
 {
-    __shared__ float4 s_vert[VANERF_NV];
     __shared__ float4 s_kpt[VANERF_NKPT];
-    for (int i = threadIdx.x; i < VANERF_NV; i += BLOCK) s_vert[i] = reinterpret_cast<const float4*>(P.f.verts)[i];
     for (int i = threadIdx.x; i < VANERF_NKPT; i += BLOCK) s_kpt[i] = reinterpret_cast<const float4*>(P.f.kpt_cam)[i];
     __syncthreads();
 
@@ -263,11 +268,19 @@ __global__ __launch_bounds__(BLOCK, 2) void query_kernel(const QueryParams P)
     const VanerfFrame& F = P.f;
     const float one_h0 = h ? 0.0f : 1.0f; // B operand of the bias k-step
 
+#ifdef VANERF_STAMPS
+    unsigned long long phase_cycles[N_PHASES] = {};
+    unsigned long long t_prev;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_prev)::"memory");
+#endif
     for (long long g = wave; g < ngroups; g += nwaves) {
-        // Opaque per-iteration copy of the (uniform) weight base: keeps LICM from hoisting the ~160 4-KB-window
-        // base addresses of the unrolled fragment stream out of the loop (they would all be live at once).
-        const float* W = P.w;
-        asm volatile("" : "+s"(W));
+        // Opaque per-iteration zero added to the (uniform, global-address-space) weight base: keeps LICM from hoisting the
+        // ~160 4-KB-window base addresses of the unrolled fragment stream out of the loop (they would all be live at
+        // once).  The offset, not the pointer, is laundered: laundering the pointer would drop its address space and turn
+        // every fragment load into a flat_load (out-of-order return => vmcnt(0) at every use).
+        unsigned opaque_zero = 0;
+        asm volatile("" : "+s"(opaque_zero));
+        const float* __restrict__ W = P.w + opaque_zero;
         const long long s_raw = g * 32 + j;
         const bool live = s_raw < P.n;
         const long long s = live ? s_raw : P.n - 1;
@@ -297,29 +310,15 @@ __global__ __launch_bounds__(BLOCK, 2) void query_kernel(const QueryParams P)
             pw = p / (p + 1e-6f);
         }
 
-        // ---- 1-NN vertex (src/networks.py:27-33): lane half h scans hand h, first minimum wins ----------
-        int nn_idx;
-        {
-            float best = INFINITY;
-            int bi_ = 0;
-            const float4* vv = s_vert + h * VANERF_NV_HAND;
-#pragma unroll 4
-            for (int i = 0; i < VANERF_NV_HAND; ++i) {
-                float4 v = vv[i];
-                float dx = px - v.x, dy = py - v.y, dz = pz - v.z;
-                float d = (dx * dx + dy * dy) + dz * dz;
-                if (d < best) { best = d; bi_ = i; }
-            }
-            bi_ += h * VANERF_NV_HAND;
-            float od = __shfl_xor(best, 32);
-            int oi = __shfl_xor(bi_, 32);
-            nn_idx = (od < best || (od == best && oi < bi_)) ? oi : bi_;
-        }
+        STAMP(0); // front end
+        // ---- 1-NN vertex (src/networks.py:27-33): found by vanerf_mesh_query_accel (same pass as the SDF) ----------
+        const int nn_idx = P.knn_in[s];
         const int tw_idx = nn_idx >= VANERF_NV_HAND ? nn_idx - VANERF_NV_HAND : nn_idx + VANERF_NV_HAND;
         const float vis_nn = F.vert_vis[nn_idx], vis_tw = F.vert_vis[tw_idx];
         const float sc0 = h ? q_vis : q_sdf;   // k-pair (sdf | qvis)
         const float sc1 = h ? vis_tw : vis_nn; // k-pair (vis_nn | vis_twin)
 
+        STAMP(1); // 1-NN
         // ---- GeoVisFusion (src/networks.py:75-106) ---------------------------------------------------------
         f32x16 g64[2], g8[1];
         {
@@ -328,7 +327,9 @@ __global__ __launch_bounds__(BLOCK, 2) void query_kernel(const QueryParams P)
             gather<8>(F.geo0, b0, 64, 32 * h, pix);
             load_row<8>(F.vfeat0 + (size_t)nn_idx * 64 + 32 * h, nn);
             load_row<8>(F.vfeat0 + (size_t)tw_idx * 64 + 32 * h, tw);
-            geo_scale<32, 2, 16>(W, P.offs, L_GEO_AT0_A, lane, h, pix, nn, tw, sc0, sc1, g64);
+            STAMP(2); // geo0 gathers
+            geo_scale<32, 2, 16>(W, P.offs, L_GEO_AT0_A, lane, pix, nn, tw, sc0, sc1, g64);
+            STAMP(3); // geo0 layers
         }
         {
             float pix[4], nn[4], tw[4];
@@ -336,8 +337,17 @@ __global__ __launch_bounds__(BLOCK, 2) void query_kernel(const QueryParams P)
             gather<1>(F.geo1, b1, 8, 4 * h, pix);
             load_row<1>(F.vfeat1 + (size_t)nn_idx * 8 + 4 * h, nn);
             load_row<1>(F.vfeat1 + (size_t)tw_idx * 8 + 4 * h, tw);
-            geo_scale<4, 1, 4>(W, P.offs, L_GEO_AT1_A, lane, h, pix, nn, tw, sc0, sc1, g8);
+            geo_scale<4, 1, 4>(W, P.offs, L_GEO_AT1_A, lane, pix, nn, tw, sc0, sc1, g8);
+            STAMP(4); // geo1
         }
+
+        // chain operand: register r of block b of a previous accumulator array, then the bias step
+        auto chain = [&](auto& src, auto tc, auto nsteps) -> float {
+            constexpr int t = decltype(tc)::value;
+            if constexpr (t < decltype(nsteps)::value) return src[t / 16][t % 16];
+            else return one_h0;
+        };
+        const unsigned v1 = (unsigned)lane, v2 = (unsigned)lane * 2, v3 = (unsigned)lane * 3, v4 = (unsigned)lane * 4;
 
         // ---- mlp_geo.layers1 (src/utils.py:822-852): [PE294 | geo64] -> 128 -> 128 -> [. | geo8] -> 120 -> 64 ----
         f32x16 xv[2];
@@ -345,108 +355,97 @@ __global__ __launch_bounds__(BLOCK, 2) void query_kernel(const QueryParams P)
             f32x16 a0[4];
             zero<4>(a0);
             {
-                WStream<4> st(W + P.offs.off[L_MLP0], lane);
-                // SpatialEncoder 'rel_z_decay' (src/spatial.py:71-72, 109-117): source-camera coordinates
+                // SpatialEncoder 'rel_z_decay' (src/spatial.py:71-72, 109-117) in source-camera coordinates; the 7
+                // features of key point i (one per lane half) are k-steps 7i..7i+6, their fragments ring slots 0..6
+                const float* base = W + P.offs.off[L_MLP0];
+                constexpr int D0 = PE_FEATS;
+                WFrag<4> ring[D0];
+                static_for<D0>([&](auto fc) { constexpr int f = decltype(fc)::value; ring[f] = wload<4>(base + f * 256 + v4); });
                 float cx = fmaf(pz, F.extrin[2], fmaf(py, F.extrin[1], px * F.extrin[0])) + F.extrin[3];
                 float cy = fmaf(pz, F.extrin[6], fmaf(py, F.extrin[5], px * F.extrin[4])) + F.extrin[7];
                 float cz = fmaf(pz, F.extrin[10], fmaf(py, F.extrin[9], px * F.extrin[8])) + F.extrin[11];
                 const float4* kp = s_kpt + h * PE_KPT_PER_HALF;
+                const float* nextp = base + D0 * 256;
                 for (int i = 0; i < PE_KPT_PER_HALF; ++i) {
                     float4 k = kp[i];
                     float ddx = cx - k.x, ddy = cy - k.y, ddz = cz - k.z;
                     float d2 = (ddx * ddx + ddy * ddy) + ddz * ddz;
                     float wk = __expf(-d2 * F.pe_inv_2sigma2);
                     float dz = F.pe_scale * ddz;
-                    float s0, c0;
-                    sincosf(dz * 3.14159274f, &s0, &c0);
-                    float s1 = 2.0f * s0 * c0, c1 = fmaf(-2.0f * s0, s0, 1.0f);
-                    float s2 = 2.0f * s1 * c1, c2 = fmaf(-2.0f * s1, s1, 1.0f);
-                    mma<4>(a0, st, dz * wk);
-                    mma<4>(a0, st, s0 * wk);
-                    mma<4>(a0, st, c0 * wk);
-                    mma<4>(a0, st, s1 * wk);
-                    mma<4>(a0, st, c1 * wk);
-                    mma<4>(a0, st, s2 * wk);
-                    mma<4>(a0, st, c2 * wk);
+                    float feat[PE_FEATS];
+                    // sin/cos(pi 2^l dz): v_sin_f32 / v_cos_f32 take revolutions, so the arguments are dz/2, dz, 2dz exactly
+                    // (|error| < 1.6e-7 absolute over the hand's extent, tools/probe_trig.hip)
+                    const float s0 = __builtin_amdgcn_sinf(0.5f * dz), c0 = __builtin_amdgcn_cosf(0.5f * dz);
+                    const float s1 = __builtin_amdgcn_sinf(dz), c1 = __builtin_amdgcn_cosf(dz);
+                    const float s2 = __builtin_amdgcn_sinf(2.0f * dz), c2 = __builtin_amdgcn_cosf(2.0f * dz);
+                    feat[0] = dz * wk; feat[1] = s0 * wk; feat[2] = c0 * wk; feat[3] = s1 * wk; feat[4] = c1 * wk;
+                    feat[5] = s2 * wk; feat[6] = c2 * wk;
+                    static_for<D0>([&](auto fc) {
+                        constexpr int f = decltype(fc)::value;
+                        const WFrag<4> a = ring[f];
+                        ring[f] = wload<4>(nextp + f * 256 + v4); // step 7(i+1)+f; after the last key point: the chain part below
+                        mfma_step<4>(a0, a, feat[f]);
+                    });
+                    nextp += D0 * 256;
                 }
-                mma_regs<4, 16>(a0, st, g64[0]);
-                mma_regs<4, 16>(a0, st, g64[1]);
-                mma<4>(a0, st, one_h0);
+                // remaining 32 + 1 steps: geo64 (two blocks) and the bias; ring slot = step % 7 (147 = 21 * 7)
+                constexpr int TREM = 33;
+                static_for<TREM>([&](auto tc) {
+                    constexpr int t = decltype(tc)::value;
+                    const float b = chain(g64, tc, std::integral_constant<int, 32>{});
+                    const WFrag<4> a = ring[t % D0];
+                    if constexpr (t + D0 < TREM) ring[t % D0] = wload<4>(nextp + t * 256 + v4);
+                    mfma_step<4>(a0, a, b);
+                });
             }
+            STAMP(5); // mlp0 (PE + geo64)
             softplus<4>(a0);
             f32x16 a1[4];
             zero<4>(a1);
-            {
-                WStream<4> st(W + P.offs.off[L_MLP1], lane);
-#pragma unroll
-                for (int b = 0; b < 4; ++b) mma_regs<4, 16>(a1, st, a0[b]);
-                mma<4>(a1, st, one_h0);
-            }
+            run_layer<4, 65>(a1, W + P.offs.off[L_MLP1], v4, [&](auto tc) -> float { return chain(a0, tc, std::integral_constant<int, 64>{}); });
             softplus<4>(a1);
             zero<4>(a0);
-            {
-                WStream<4> st(W + P.offs.off[L_MLP2], lane);
-#pragma unroll
-                for (int b = 0; b < 4; ++b) mma_regs<4, 16>(a0, st, a1[b]);
-                mma_regs<4, 4>(a0, st, g8[0]);
-                mma<4>(a0, st, one_h0);
-            }
+            run_layer<4, 69>(a0, W + P.offs.off[L_MLP2], v4, [&](auto tc) -> float {
+                constexpr int t = decltype(tc)::value;
+                if constexpr (t < 64) return a1[t / 16][t % 16];
+                else if constexpr (t < 68) return g8[0][t - 64];
+                else return one_h0;
+            });
             softplus<4>(a0);
             zero<2>(xv);
-            {
-                WStream<2> st(W + P.offs.off[L_MLP3], lane);
-#pragma unroll
-                for (int b = 0; b < 3; ++b) mma_regs<2, 16>(xv, st, a0[b]);
-                mma_regs<2, 12>(xv, st, a0[3]);
-                mma<2>(xv, st, one_h0);
-            }
+            run_layer<2, 61>(xv, W + P.offs.off[L_MLP3], v2, [&](auto tc) -> float { return chain(a0, tc, std::integral_constant<int, 60>{}); });
         }
+        STAMP(6); // softplus x3 + mlp1..3
         // ---- PoolModule mean/var over V = 1 views (src/utils.py:744-779, 854-880) --------------------------
-        f32x16 mean[2], var[2];
+        f32x16 pool[4]; // [mean64 | var64]
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 float m = pw * xv[b][r];
                 float d = xv[b][r] - m;
-                mean[b][r] = m;
-                var[b][r] = pw * (d * d);
+                pool[b][r] = m;
+                pool[2 + b][r] = pw * (d * d);
             }
         // ---- mlp_geo.layers2: 128 -> 64 -> 64 -> 2 (src/utils.py:709-719) ----------------------------------
         f32x16 head[1];
         {
             f32x16 m0[2], m1[2];
             zero<2>(m0);
-            {
-                WStream<2> st(W + P.offs.off[L_HEAD0], lane);
-                mma_regs<2, 16>(m0, st, mean[0]); mma_regs<2, 16>(m0, st, mean[1]);
-                mma_regs<2, 16>(m0, st, var[0]);  mma_regs<2, 16>(m0, st, var[1]);
-                mma<2>(m0, st, one_h0);
-            }
+            run_layer<2, 65>(m0, W + P.offs.off[L_HEAD0], v2, [&](auto tc) -> float { return chain(pool, tc, std::integral_constant<int, 64>{}); });
             softplus<2>(m0);
             zero<2>(m1);
-            {
-                WStream<2> st(W + P.offs.off[L_HEAD1], lane);
-                mma_regs<2, 16>(m1, st, m0[0]); mma_regs<2, 16>(m1, st, m0[1]);
-                mma<2>(m1, st, one_h0);
-            }
+            run_layer<2, 33>(m1, W + P.offs.off[L_HEAD1], v2, [&](auto tc) -> float { return chain(m0, tc, std::integral_constant<int, 32>{}); });
             softplus<2>(m1);
             zero<1>(head);
-            {
-                WStream<1> st(W + P.offs.off[L_HEAD2], lane);
-                mma_regs<1, 16>(head, st, m1[0]); mma_regs<1, 16>(head, st, m1[1]);
-                mma<1>(head, st, one_h0);
-            }
+            run_layer<1, 33>(head, W + P.offs.off[L_HEAD2], v1, [&](auto tc) -> float { return chain(m1, tc, std::integral_constant<int, 32>{}); });
         }
+        STAMP(7); // pool + head
         // ---- ibr_compress_gfeat 128 -> 24 (src/model.py:921) ------------------------------------------------
         f32x16 lat[1];
         zero<1>(lat);
-        {
-            WStream<1> st(W + P.offs.off[L_IBR], lane);
-            mma_regs<1, 16>(lat, st, mean[0]); mma_regs<1, 16>(lat, st, mean[1]);
-            mma_regs<1, 16>(lat, st, var[0]);  mma_regs<1, 16>(lat, st, var[1]);
-            mma<1>(lat, st, one_h0);
-        }
+        run_layer<1, 65>(lat, W + P.offs.off[L_IBR], v1, [&](auto tc) -> float { return chain(pool, tc, std::integral_constant<int, 64>{}); });
+        STAMP(8); // ibr
         // ---- TexVisFusion per-sample part (src/networks.py:281-293) -----------------------------------------
         f32x16 rgb[1];
         {
@@ -461,26 +460,22 @@ __global__ __launch_bounds__(BLOCK, 2) void query_kernel(const QueryParams P)
             q[3] = h ? qt[6] : qt[0]; q[4] = h ? qt[7] : qt[1]; q[5] = h ? 0.0f : qt[2];
             const float t0 = h ? vis_nn : q_vis; // k-pair (qvis | vis_nn)
             const float t1 = h ? 0.0f : vis_tw;  // k-pair (vis_twin | -)
+            f32x16 latg = lat[0];
+            auto tex_in = [&](auto tc) -> float {
+                constexpr int t = decltype(tc)::value;
+                if constexpr (t < 29) return row[t];
+                else if constexpr (t < 35) return q[t - 29];
+                else if constexpr (t < 47) return latg[t - 35];
+                else if constexpr (t == 47) return t0;
+                else return t1;
+            };
             f32x16 ta[3];
             zero<3>(ta);
-            {
-                WStream<3> st(W + P.offs.off[L_TEX_AT_A], lane);
-#pragma unroll
-                for (int t = 0; t < 29; ++t) mma<3>(ta, st, row[t]);
-#pragma unroll
-                for (int t = 0; t < 6; ++t) mma<3>(ta, st, q[t]);
-                mma_regs<3, 12>(ta, st, lat[0]);
-                mma<3>(ta, st, t0);
-                mma<3>(ta, st, t1);
-            }
+            run_layer<3, 49>(ta, W + P.offs.off[L_TEX_AT_A], v3, tex_in);
             relu<3>(ta);
             f32x16 tg[1];
             zero<1>(tg);
-            {
-                WStream<1> st(W + P.offs.off[L_TEX_AT_B], lane);
-#pragma unroll
-                for (int b = 0; b < 3; ++b) mma_regs<1, 16>(tg, st, ta[b]);
-            }
+            run_layer<1, 48>(tg, W + P.offs.off[L_TEX_AT_B], v1, [&](auto tc) -> float { constexpr int t = decltype(tc)::value; return ta[t / 16][t % 16]; });
             // six gates: rows 0..3 -> h = 0 lanes regs 0..3, rows 4,5 -> h = 1 lanes regs 0,1
             float m0 = sigmoid_f(tg[0][0]), m1 = sigmoid_f(tg[0][1]), m2 = sigmoid_f(tg[0][2]), m3 = sigmoid_f(tg[0][3]);
             float o0 = __shfl_xor(m0, 32), o1 = __shfl_xor(m1, 32), o2 = __shfl_xor(m2, 32);
@@ -494,28 +489,15 @@ __global__ __launch_bounds__(BLOCK, 2) void query_kernel(const QueryParams P)
             for (int t = 11; t < 29; ++t) row[t] *= ggf;
 #pragma unroll
             for (int t = 0; t < 6; ++t) q[t] *= gq;
-            f32x16 latg;
 #pragma unroll
             for (int r = 0; r < 12; ++r) latg[r] = lat[0][r] * glat;
             zero<3>(ta);
-            {
-                WStream<3> st(W + P.offs.off[L_TEX_A], lane);
-#pragma unroll
-                for (int t = 0; t < 29; ++t) mma<3>(ta, st, row[t]);
-#pragma unroll
-                for (int t = 0; t < 6; ++t) mma<3>(ta, st, q[t]);
-                mma_regs<3, 12>(ta, st, latg);
-                mma<3>(ta, st, t0);
-                mma<3>(ta, st, t1);
-            }
+            run_layer<3, 49>(ta, W + P.offs.off[L_TEX_A], v3, tex_in);
             relu<3>(ta);
             zero<1>(rgb);
-            {
-                WStream<1> st(W + P.offs.off[L_TEX_B], lane);
-#pragma unroll
-                for (int b = 0; b < 3; ++b) mma_regs<1, 16>(rgb, st, ta[b]);
-            }
+            run_layer<1, 48>(rgb, W + P.offs.off[L_TEX_B], v1, [&](auto tc) -> float { constexpr int t = decltype(tc)::value; return ta[t / 16][t % 16]; });
         }
+        STAMP(9); // tex
         // ---- eval_func (src/model.py:1140-1160): rows 0,1 of the head / 0..2 of the colour live in the h = 0 lanes ----
         if (live && h == 0) {
             float rad = head[0][1];
@@ -527,19 +509,23 @@ __global__ __launch_bounds__(BLOCK, 2) void query_kernel(const QueryParams P)
             o[3] = rgb[0][1];
             o[4] = rgb[0][2];
             if (P.valid) P.valid[s] = mask > 0.0f;
-            if (P.knn_idx) P.knn_idx[s] = nn_idx;
         }
+        STAMP(10); // store
     }
+#ifdef VANERF_STAMPS
+    if (P.stamps && lane == 0)
+        for (int k = 0; k < N_PHASES; ++k) P.stamps[wave * N_PHASES + k] = phase_cycles[k];
+#endif
 }
 
 } // namespace
 
 extern "C" int vanerf_query_samples(const VanerfWeights* w, const VanerfFrame* frame, const float* pts, const float* query_sdf,
-                                    const uint8_t* query_vis, const float* noise, int64_t n, float* out, uint8_t* valid,
-                                    int32_t* knn_idx, void* stream)
+                                    const uint8_t* query_vis, const int32_t* knn_idx, const float* noise, int64_t n, float* out,
+                                    uint8_t* valid, void* stream)
 {
     return guarded([&] {
-        if (!w || !w->dev || !frame || !pts || !query_sdf || !query_vis || !out) throw_error("vanerf_query_samples: null argument");
+        if (!w || !w->dev || !frame || !pts || !query_sdf || !query_vis || !knn_idx || !out) throw_error("vanerf_query_samples: null argument");
         if (n < 0) throw_error("vanerf_query_samples: n = %lld < 0", (long long)n);
         if (n == 0) return;
         const VanerfFrame& f = *frame;
@@ -548,8 +534,8 @@ extern "C" int vanerf_query_samples(const VanerfWeights* w, const VanerfFrame* f
         if (f.h0 < 1 || f.w0 < 1 || f.h1 < 1 || f.w1 < 1 || f.ht < 1 || f.wt < 1 || f.hi < 1 || f.wi < 1)
             throw_error("vanerf_query_samples: feature-map sizes must be positive");
         QueryParams P;
-        P.f = f; P.w = w->dev; P.offs = w->offs; P.pts = pts; P.qsdf = query_sdf; P.qvis = query_vis; P.noise = noise;
-        P.n = n; P.out = out; P.valid = valid; P.knn_idx = knn_idx;
+        P.f = f; P.w = w->dev; P.offs = w->offs; P.pts = pts; P.qsdf = query_sdf; P.qvis = query_vis; P.noise = noise; P.knn_in = knn_idx;
+        P.n = n; P.out = out; P.valid = valid; P.stamps = nullptr;
         long long ngroups = (n + 31) / 32;
         long long blocks = (ngroups + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
         int dev = 0, cus = 256;
@@ -561,3 +547,22 @@ extern "C" int vanerf_query_samples(const VanerfWeights* w, const VanerfFrame* f
         HIP_CHECK(hipGetLastError());
     });
 }
+
+#ifdef VANERF_STAMPS
+// Diagnostic build: same launch with a per-wave phase-cycle table [waves][12] (device pointer, zero-initialised by the caller).
+extern "C" int vanerf_debug_query_stamps(const VanerfWeights* w, const VanerfFrame* frame, const float* pts, const float* query_sdf,
+                                         const uint8_t* query_vis, const int32_t* knn_idx, int64_t n, float* out, unsigned long long* stamps, int* n_waves, void* stream)
+{
+    return guarded([&] {
+        QueryParams P;
+        P.f = *frame; P.w = w->dev; P.offs = w->offs; P.pts = pts; P.qsdf = query_sdf; P.qvis = query_vis; P.noise = nullptr; P.knn_in = knn_idx;
+        P.n = n; P.out = out; P.valid = nullptr; P.stamps = stamps;
+        long long ngroups = (n + 31) / 32;
+        long long blocks = (ngroups + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
+        if (blocks > 512) blocks = 512;
+        *n_waves = (int)blocks * WAVES_PER_BLOCK;
+        if (stamps) hipLaunchKernelGGL(query_kernel, dim3((unsigned)blocks), dim3(BLOCK), 0, (hipStream_t)stream, P);
+        HIP_CHECK(hipGetLastError());
+    });
+}
+#endif

@@ -205,7 +205,18 @@ class MeshAccel:
         self.cell_tri = pairs[:, 1].to(torch.int32).contiguous()
         if self.cell_tri.numel() == 0:
             self.cell_tri = torch.zeros(1, dtype=torch.int32, device=dev)
+        # vertex clusters for the 1-NN search (original index carried in .w as int bits)
+        nv = verts3.shape[0]
+        qv = ((verts3 - lo) / (hi - lo + 1e-9) * 1023.0).long().clamp(0, 1023)
+        vorder = torch.argsort(_part1by2(qv[:, 0]) | (_part1by2(qv[:, 1]) << 1) | (_part1by2(qv[:, 2]) << 2), stable=True)
+        nvp = (nv + self.CL - 1) // self.CL * self.CL
+        vs = torch.cat([verts3[vorder], torch.full((nvp - nv, 3), 1.0e4, device=dev)], 0)
+        vidx = torch.cat([vorder.to(torch.int32), torch.full((nvp - nv,), 0x7FFFFFFF, dtype=torch.int32, device=dev)])
+        self.vsort = torch.cat([vs, vidx.view(torch.float32)[:, None]], 1).contiguous()
+        vcl = vs.reshape(nvp // self.CL, self.CL, 3)
+        self.vbox = torch.cat([vcl.min(1)[0], vcl.max(1)[0]], 1).contiguous()
         c = VanerfMeshAccel()
+        c.vsort, c.vbox, c.nvc = _ptr(self.vsort, f32), _ptr(self.vbox, f32), nvp // self.CL
         c.tri, c.sphere, c.orig, c.cbox = _ptr(self.tri, f32), _ptr(self.sphere, f32), _ptr(self.orig, torch.int32), _ptr(self.cbox, f32)
         c.nfp, c.nc = nfp, nfp // self.CL
         c.cell_start, c.cell_tri = _ptr(self.cell_start, torch.int32), _ptr(self.cell_tri, torch.int32)
@@ -306,16 +317,17 @@ def mesh_query(verts3, faces_i32, vert_vis, pts, want_face=False):
     return (sdf, vis, face) if want_face else (sdf, vis)
 
 
-def mesh_query_accel(accel, verts3, faces_i32, vert_vis, pts, want_face=False):
-    """Same results as mesh_query, through the per-frame acceleration structure."""
+def mesh_query_accel(accel, verts3, faces_i32, vert_vis, pts, want_face=False, want_knn=True):
+    """Same results as mesh_query (+ knn1), through the per-frame acceleration structure: sdf, vis[, face][, knn]."""
     n = pts.shape[0]
     sdf = torch.empty(n, dtype=torch.float32, device=pts.device)
     vis = torch.empty(n, dtype=torch.uint8, device=pts.device)
     face = torch.empty(n, dtype=torch.int32, device=pts.device) if want_face else None
+    knn = torch.empty(n, dtype=torch.int32, device=pts.device) if want_knn else None
     check(lib.vanerf_mesh_query_accel(byref(accel.c), _ptr(verts3, torch.float32), verts3.shape[0], _ptr(faces_i32, torch.int32),
                                       faces_i32.shape[0], _ptr(vert_vis, torch.float32), _ptr(pts, torch.float32), n, _ptr(sdf), _ptr(vis),
-                                      _ptr(face), _stream()))
-    return (sdf, vis, face) if want_face else (sdf, vis)
+                                      _ptr(face), _ptr(knn), _stream()))
+    return tuple(t for t in (sdf, vis, face, knn) if t is not None)
 
 
 def knn1(verts4, pts):
@@ -324,20 +336,15 @@ def knn1(verts4, pts):
     return idx
 
 
-def query_samples(weights, frame, pts, query_sdf, query_vis, noise=None, want_valid=False, want_knn=False):
-    """VANeRF.query + eval_func (src/model.py:748-957, 1140-1160): (N,3),(N,),(N,)u8 -> (N,5) [alpha, sdf, r, g, b]."""
+def query_samples(weights, frame, pts, query_sdf, query_vis, knn_idx, noise=None, want_valid=False):
+    """VANeRF.query + eval_func (src/model.py:748-957, 1140-1160): (N,3),(N,),(N,)u8,(N,)i32 -> (N,5) [alpha, sdf, r, g, b]."""
     n = pts.shape[0]
     out = torch.empty(n, 5, dtype=torch.float32, device=pts.device)
     valid = torch.empty(n, dtype=torch.uint8, device=pts.device) if want_valid else None
-    knn = torch.empty(n, dtype=torch.int32, device=pts.device) if want_knn else None
     check(lib.vanerf_query_samples(weights.handle, byref(frame.c), _ptr(pts, torch.float32), _ptr(query_sdf, torch.float32),
-                                   _ptr(query_vis, torch.uint8), _ptr(noise, torch.float32), n, _ptr(out), _ptr(valid), _ptr(knn), _stream()))
-    res = [out]
-    if want_valid:
-        res.append(valid)
-    if want_knn:
-        res.append(knn)
-    return res[0] if len(res) == 1 else tuple(res)
+                                   _ptr(query_vis, torch.uint8), _ptr(knn_idx, torch.int32), _ptr(noise, torch.float32), n, _ptr(out),
+                                   _ptr(valid), _stream()))
+    return (out, valid) if want_valid else out
 
 
 def composite(rgba, z, mesh_sdf, beta, want_contrib=True):
@@ -430,14 +437,14 @@ def render_pass(weights, frame, cam_tar, bounds, x0, y0, step, nx, ny, sample_pe
 
     def evaluate(z):
         pts = sample_points(rays["rays_d"], rays["cam_pos"], z)
-        q_sdf, q_vis = mesh_query_accel(frame.accel, frame.verts3, frame.faces, frame.vert_vis, pts)
+        q_sdf, q_vis, knn = mesh_query_accel(frame.accel, frame.verts3, frame.faces, frame.vert_vis, pts)
         noise = None
         if noise_std > 0.0:  # th.randn_like(rad) * rand_noise_std (src/model.py:1155-1156), drawn on the device
             noise = torch.randn(pts.shape[0], device=pts.device, generator=generator) * noise_std
         if kernel_events is not None:  # HIP events around the dominant kernel, on the stream it is launched on
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        rgba = query_samples(weights, frame, pts, q_sdf, q_vis, noise)
+        rgba = query_samples(weights, frame, pts, q_sdf, q_vis, knn, noise)
         if kernel_events is not None:
             e1.record()
             kernel_events.append((e0, e1, pts.shape[0]))
