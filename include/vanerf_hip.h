@@ -115,6 +115,12 @@ int vanerf_ray_setup(int x0, int y0, int step_x, int step_y, int nx, int ny, int
                      int64_t* index, float* rays_d, float* cam_pos, float* near, float* far, uint8_t* hit, float* z,
                      void* stream);
 
+/* Same with an explicit pixel list pixels_xy[n_rays][2] (int32, device): the training branch's clamped 64x64 window around a
+ * random mask pixel (src/model.py:1172-1189) is not a regular grid.                                                         */
+int vanerf_ray_setup_pixels(const int32_t* pixels_xy, int n_rays, int width, const float* invK_T, const float* RT, float znear,
+                            float zfar, const float* bounds, int S, const float* t_lin, const float* jitter, int64_t* index,
+                            float* rays_d, float* cam_pos, float* near, float* far, uint8_t* hit, float* z, void* stream);
+
 /* eval_pts = cam_pos + dir * z (src/model.py:1234-1235).  pts[R*S][3]. */
 int vanerf_sample_points(const float* rays_d, const float* cam_pos, const float* z, int R, int S, float* pts, void* stream);
 
@@ -156,9 +162,10 @@ int vanerf_knn1(const float* verts4, int nv, const float* pts, int64_t n, int32_
 /* a7-a15  VANeRF.query + eval_func for N samples (src/model.py:748-957, 1140-1160), n_views = 1:
  *     pts[N][3], query_sdf[N], query_vis[N] (u8), knn_idx[N] (1-NN vertex, from vanerf_mesh_query_accel or vanerf_knn1),
  *     noise[N] or NULL (rand_noise_std draws, model.py:1156)
- *     -> out[N][5] = [alpha, sdf, r, g, b];  valid[N] (u8, may be NULL)                                                  */
+ *     raw = 0 -> out[N][5] = [alpha, sdf, r, g, b] (eval_func applied);  raw = 1 -> [sdf_pred, rad, r, g, b] as VANeRF.query returns
+ *     valid[N] (u8, may be NULL)                                                                                          */
 int vanerf_query_samples(const VanerfWeights* w, const VanerfFrame* frame, const float* pts, const float* query_sdf,
-                         const uint8_t* query_vis, const int32_t* knn_idx, const float* noise, int64_t n, float* out,
+                         const uint8_t* query_vis, const int32_t* knn_idx, const float* noise, int raw, int64_t n, float* out,
                          uint8_t* valid, void* stream);
 
 /* a16  sdf_activation + rgba2out (src/model.py:879-882, 1464-1494):
@@ -179,6 +186,15 @@ int vanerf_composite_merged(const float* rgba_c, const float* mesh_sdf_c, int Sc
  *     idx[R][Sf] int32 searchsorted index after clamping (may be NULL)                                                   */
 int vanerf_importance_merge(const float* contrib, const float* z, const float* u, const float* t_lin, int R, int Sc, int Sf,
                             float* z_new, float* z_fine, int32_t* src, int32_t* idx, void* stream);
+
+/* a17 in the reference's own call shape (src/model.py:1304, 1424-1462): contrib_inner[R][n_bins] = contrib[..., 1:-1],
+ *     z_mid[R][n_bins+1] -> z_new[R][Sf]; idx[R][Sf] (searchsorted index after clamping, may be NULL).                     */
+int vanerf_importance_sample(const float* contrib_inner, const float* z_mid, const float* u, const float* t_lin, int R, int n_bins,
+                             int Sf, float* z_new, int32_t* idx, void* stream);
+
+/* a3  ray_bbox_intersection (src/model.py:1496-1570) alone: bounds[6], orig[3] (host values), dirs[R][3] (device)
+ *     -> near[R], far[R] (1.0 when the ray does not cross the box exactly twice), hit[R] (u8).                               */
+int vanerf_ray_bbox(const float* bounds, const float* orig, const float* dirs, int R, float* near, float* far, uint8_t* hit, void* stream);
 
 #ifdef __cplusplus
 }

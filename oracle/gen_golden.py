@@ -76,6 +76,15 @@ def main():
     missing = net.load_state_dict(synth.make_hot_weights(0), strict=False)
     assert not missing.unexpected_keys
     sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    # full key/shape inventory of the reference module (drop-in contract: checkpoints must load unchanged)
+    with open(os.path.join(OUT, "state_dict_keys.json"), "w") as f:
+        json.dump({k: list(v.shape) for k, v in sd.items()}, f, indent=0)
+    # encoder outputs for the 256x256 source image (shape contract of attach_geo_feat / attach_tex_feat)
+    with torch.no_grad():
+        fg = net.attach_geo_feat(torch.rand(1, 3, 256, 256), return_val=True)
+        ft = net.attach_tex_feat(torch.rand(1, 3, 256, 256), return_val=True)
+    with open(os.path.join(OUT, "encoder_shapes.json"), "w") as f:
+        json.dump({"feat_geo": [list(t.shape) for t in fg], "feat_tex": list(ft.shape)}, f)
     hot = {k: v for k, v in sd.items() if k.startswith(HOT_PREFIXES)}
     save("weights_hot", **hot)
     big = {k: v for k, v in sd.items() if k.startswith("tex_vis_fusion.") and k not in hot}

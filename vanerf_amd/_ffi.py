@@ -58,15 +58,19 @@ _SIGS = {
     "vanerf_weights_pack_host": (c_int, [POINTER(VanerfWeightTable), _FP, c_int64, POINTER(c_int64), POINTER(c_uint)]),
     "vanerf_ray_setup": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, POINTER(c_float), POINTER(c_float), c_float, c_float,
                                  POINTER(c_float), c_int, _FP, _FP, _FP, _FP, _FP, _FP, _FP, _FP, _FP, c_void_p]),
+    "vanerf_ray_setup_pixels": (c_int, [_FP, c_int, c_int, POINTER(c_float), POINTER(c_float), c_float, c_float, POINTER(c_float), c_int, _FP, _FP,
+                                        _FP, _FP, _FP, _FP, _FP, _FP, _FP, c_void_p]),
     "vanerf_sample_points": (c_int, [_FP, _FP, _FP, c_int, c_int, _FP, c_void_p]),
     "vanerf_vertex_visibility": (c_int, [_FP, _FP, c_int, _FP, c_int, c_int, _FP, _FP, c_void_p]),
     "vanerf_mesh_query": (c_int, [_FP, c_int, _FP, c_int, _FP, _FP, c_int64, _FP, _FP, _FP, c_void_p]),
     "vanerf_mesh_query_accel": (c_int, [POINTER(VanerfMeshAccel), _FP, c_int, _FP, c_int, _FP, _FP, c_int64, _FP, _FP, _FP, _FP, c_void_p]),
     "vanerf_knn1": (c_int, [_FP, c_int, _FP, c_int64, _FP, c_void_p]),
-    "vanerf_query_samples": (c_int, [c_void_p, POINTER(VanerfFrame), _FP, _FP, _FP, _FP, _FP, c_int64, _FP, _FP, c_void_p]),
+    "vanerf_query_samples": (c_int, [c_void_p, POINTER(VanerfFrame), _FP, _FP, _FP, _FP, _FP, c_int, c_int64, _FP, _FP, c_void_p]),
     "vanerf_composite": (c_int, [_FP, _FP, _FP, c_int, c_int, c_float, _FP, _FP, _FP, _FP, _FP, c_void_p]),
     "vanerf_composite_merged": (c_int, [_FP, _FP, c_int, _FP, _FP, c_int, _FP, _FP, c_int, c_float, _FP, _FP, _FP, _FP, _FP, c_void_p]),
     "vanerf_importance_merge": (c_int, [_FP, _FP, _FP, _FP, c_int, c_int, c_int, _FP, _FP, _FP, _FP, c_void_p]),
+    "vanerf_importance_sample": (c_int, [_FP, _FP, _FP, _FP, c_int, c_int, c_int, _FP, _FP, c_void_p]),
+    "vanerf_ray_bbox": (c_int, [POINTER(c_float), POINTER(c_float), _FP, c_int, _FP, _FP, _FP, c_void_p]),
 }
 EXPORTS = tuple(_SIGS)
 

@@ -50,6 +50,7 @@ struct QueryParams {
     const uint8_t* qvis;
     const float* noise;
     const int32_t* knn_in;
+    int raw; // 1: write [sdf_pred, rad, r, g, b] (VANeRF.query), 0: eval_func applied ([alpha, sdf, r, g, b])
     long long n;
     float* out;
     uint8_t* valid;
@@ -503,8 +504,8 @@ __global__ __launch_bounds__(BLOCK, 2) void query_kernel(const QueryParams P)
             float rad = head[0][1];
             if (P.noise) rad += P.noise[s];
             float* o = P.out + 5 * s;
-            o[0] = mask * fmaxf(rad, 0.0f);
-            o[1] = mask * head[0][0] + (1.0f - mask) * F.invalid_sdf;
+            o[0] = P.raw ? head[0][0] : mask * fmaxf(rad, 0.0f);
+            o[1] = P.raw ? head[0][1] : mask * head[0][0] + (1.0f - mask) * F.invalid_sdf;
             o[2] = rgb[0][0];
             o[3] = rgb[0][1];
             o[4] = rgb[0][2];
@@ -521,7 +522,7 @@ __global__ __launch_bounds__(BLOCK, 2) void query_kernel(const QueryParams P)
 } // namespace
 
 extern "C" int vanerf_query_samples(const VanerfWeights* w, const VanerfFrame* frame, const float* pts, const float* query_sdf,
-                                    const uint8_t* query_vis, const int32_t* knn_idx, const float* noise, int64_t n, float* out,
+                                    const uint8_t* query_vis, const int32_t* knn_idx, const float* noise, int raw, int64_t n, float* out,
                                     uint8_t* valid, void* stream)
 {
     return guarded([&] {
@@ -534,7 +535,7 @@ extern "C" int vanerf_query_samples(const VanerfWeights* w, const VanerfFrame* f
         if (f.h0 < 1 || f.w0 < 1 || f.h1 < 1 || f.w1 < 1 || f.ht < 1 || f.wt < 1 || f.hi < 1 || f.wi < 1)
             throw_error("vanerf_query_samples: feature-map sizes must be positive");
         QueryParams P;
-        P.f = f; P.w = w->dev; P.offs = w->offs; P.pts = pts; P.qsdf = query_sdf; P.qvis = query_vis; P.noise = noise; P.knn_in = knn_idx;
+        P.f = f; P.w = w->dev; P.offs = w->offs; P.pts = pts; P.qsdf = query_sdf; P.qvis = query_vis; P.noise = noise; P.knn_in = knn_idx; P.raw = raw;
         P.n = n; P.out = out; P.valid = valid; P.stamps = nullptr;
         long long ngroups = (n + 31) / 32;
         long long blocks = (ngroups + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
@@ -555,7 +556,7 @@ extern "C" int vanerf_debug_query_stamps(const VanerfWeights* w, const VanerfFra
 {
     return guarded([&] {
         QueryParams P;
-        P.f = *frame; P.w = w->dev; P.offs = w->offs; P.pts = pts; P.qsdf = query_sdf; P.qvis = query_vis; P.noise = nullptr; P.knn_in = knn_idx;
+        P.f = *frame; P.w = w->dev; P.offs = w->offs; P.pts = pts; P.qsdf = query_sdf; P.qvis = query_vis; P.noise = nullptr; P.knn_in = knn_idx; P.raw = 0;
         P.n = n; P.out = out; P.valid = nullptr; P.stamps = stamps;
         long long ngroups = (n + 31) / 32;
         long long blocks = (ngroups + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;

@@ -13,6 +13,7 @@ namespace {
 
 struct RayParams {
     int x0, y0, step_x, step_y, nx, ny, width;
+    const int32_t* pixels; // optional explicit (x, y) list of nx*ny pixels (training patches), else the regular grid
     float invK_T[9];
     float RT[12];
     float znear, zfar;
@@ -31,42 +32,12 @@ struct RayParams {
 
 __device__ __forceinline__ float norm3(float a, float b, float c) { return sqrtf((a * a + b * b) + c * c); }
 
-__global__ void ray_setup_kernel(const RayParams P)
+// ray_bbox_intersection (src/model.py:1496-1570): bounds +-(0.01), |d| < 1e-5 -> 1e-5, six plane hits, inside test with
+// eps 1e-6, valid iff exactly two hits; near/far = min/max of |p - o| / |d|, else 1.0.
+__device__ __forceinline__ bool ray_bbox(const float* bounds, float ox, float oy, float oz, float dx, float dy, float dz, float& z1, float& z2)
 {
-    const int R = P.nx * P.ny;
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    // camera centre: -(t . R)  (src/model.py:1213)
-    const float* M = P.RT;
-    const float tx = M[3], ty = M[7], tz = M[11];
-    const float ox = -((tx * M[0] + ty * M[4]) + tz * M[8]);
-    const float oy = -((tx * M[1] + ty * M[5]) + tz * M[9]);
-    const float oz = -((tx * M[2] + ty * M[6]) + tz * M[10]);
-    if (r == 0) { P.cam_pos[0] = ox; P.cam_pos[1] = oy; P.cam_pos[2] = oz; }
-    if (r >= R) return;
-    const int ix = r % P.nx, iy = r / P.nx;
-    const int gxi = P.x0 + ix * P.step_x, gyi = P.y0 + iy * P.step_y;
-    P.index[r] = (int64_t)gxi + (int64_t)gyi * P.width;
-    const float gx = (float)gxi, gy = (float)gyi;
-    const float* K = P.invK_T; // row-major 3x3: c_j = gx*K[0][j] + gy*K[1][j] + K[2][j]
-    float c0 = (gx * K[0] + gy * K[3]) + K[6];
-    float c1 = (gx * K[1] + gy * K[4]) + K[7];
-    float c2 = (gx * K[2] + gy * K[5]) + K[8];
-    // znear/zfar along the ray: || (z * [x, y, 1]) K^-T ||  (src/model.py:1204-1211)
-    float nx_ = P.znear * gx, ny_ = P.znear * gy, nz_ = P.znear;
-    float zn = norm3((nx_ * K[0] + ny_ * K[3]) + nz_ * K[6], (nx_ * K[1] + ny_ * K[4]) + nz_ * K[7], (nx_ * K[2] + ny_ * K[5]) + nz_ * K[8]);
-    float fx_ = P.zfar * gx, fy_ = P.zfar * gy, fz_ = P.zfar;
-    float zf = norm3((fx_ * K[0] + fy_ * K[3]) + fz_ * K[6], (fx_ * K[1] + fy_ * K[4]) + fz_ * K[7], (fx_ * K[2] + fy_ * K[5]) + fz_ * K[8]);
-    // world direction: normalize(c . R)
-    float dx = (c0 * M[0] + c1 * M[4]) + c2 * M[8];
-    float dy = (c0 * M[1] + c1 * M[5]) + c2 * M[9];
-    float dz = (c0 * M[2] + c1 * M[6]) + c2 * M[10];
-    float nrm = fmaxf(norm3(dx, dy, dz), 1e-12f);
-    dx /= nrm; dy /= nrm; dz /= nrm;
-    P.rays_d[3 * r] = dx; P.rays_d[3 * r + 1] = dy; P.rays_d[3 * r + 2] = dz;
-
-    // ray_bbox_intersection (src/model.py:1496-1570)
-    const float lo[3] = {P.bounds[0] - 0.01f, P.bounds[1] - 0.01f, P.bounds[2] - 0.01f};
-    const float hi[3] = {P.bounds[3] + 0.01f, P.bounds[4] + 0.01f, P.bounds[5] + 0.01f};
+    const float lo[3] = {bounds[0] - 0.01f, bounds[1] - 0.01f, bounds[2] - 0.01f};
+    const float hi[3] = {bounds[3] + 0.01f, bounds[4] + 0.01f, bounds[5] + 0.01f};
     float d[3] = {dx, dy, dz};
     const float o[3] = {ox, oy, oz};
 #pragma unroll
@@ -90,8 +61,59 @@ __global__ void ray_setup_kernel(const RayParams P)
         }
     }
     const bool hit = cnt == 2;
-    const float z1 = hit ? fminf(dist[0], dist[1]) : 1.0f;
-    const float z2 = hit ? fmaxf(dist[0], dist[1]) : 1.0f;
+    z1 = hit ? fminf(dist[0], dist[1]) : 1.0f;
+    z2 = hit ? fmaxf(dist[0], dist[1]) : 1.0f;
+    return hit;
+}
+
+struct BboxParams { float bounds[6]; float o[3]; };
+
+__global__ void ray_bbox_kernel(const BboxParams B, const float* __restrict__ dirs, int R, float* __restrict__ near, float* __restrict__ far,
+                                uint8_t* __restrict__ hit)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    float z1, z2;
+    const bool h = ray_bbox(B.bounds, B.o[0], B.o[1], B.o[2], dirs[3 * r], dirs[3 * r + 1], dirs[3 * r + 2], z1, z2);
+    near[r] = z1; far[r] = z2; hit[r] = h;
+}
+
+__global__ void ray_setup_kernel(const RayParams P)
+{
+    const int R = P.nx * P.ny;
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    // camera centre: -(t . R)  (src/model.py:1213)
+    const float* M = P.RT;
+    const float tx = M[3], ty = M[7], tz = M[11];
+    const float ox = -((tx * M[0] + ty * M[4]) + tz * M[8]);
+    const float oy = -((tx * M[1] + ty * M[5]) + tz * M[9]);
+    const float oz = -((tx * M[2] + ty * M[6]) + tz * M[10]);
+    if (r == 0) { P.cam_pos[0] = ox; P.cam_pos[1] = oy; P.cam_pos[2] = oz; }
+    if (r >= R) return;
+    const int ix = r % P.nx, iy = r / P.nx;
+    const int gxi = P.pixels ? P.pixels[2 * r] : P.x0 + ix * P.step_x;
+    const int gyi = P.pixels ? P.pixels[2 * r + 1] : P.y0 + iy * P.step_y;
+    P.index[r] = (int64_t)gxi + (int64_t)gyi * P.width;
+    const float gx = (float)gxi, gy = (float)gyi;
+    const float* K = P.invK_T; // row-major 3x3: c_j = gx*K[0][j] + gy*K[1][j] + K[2][j]
+    float c0 = (gx * K[0] + gy * K[3]) + K[6];
+    float c1 = (gx * K[1] + gy * K[4]) + K[7];
+    float c2 = (gx * K[2] + gy * K[5]) + K[8];
+    // znear/zfar along the ray: || (z * [x, y, 1]) K^-T ||  (src/model.py:1204-1211)
+    float nx_ = P.znear * gx, ny_ = P.znear * gy, nz_ = P.znear;
+    float zn = norm3((nx_ * K[0] + ny_ * K[3]) + nz_ * K[6], (nx_ * K[1] + ny_ * K[4]) + nz_ * K[7], (nx_ * K[2] + ny_ * K[5]) + nz_ * K[8]);
+    float fx_ = P.zfar * gx, fy_ = P.zfar * gy, fz_ = P.zfar;
+    float zf = norm3((fx_ * K[0] + fy_ * K[3]) + fz_ * K[6], (fx_ * K[1] + fy_ * K[4]) + fz_ * K[7], (fx_ * K[2] + fy_ * K[5]) + fz_ * K[8]);
+    // world direction: normalize(c . R)
+    float dx = (c0 * M[0] + c1 * M[4]) + c2 * M[8];
+    float dy = (c0 * M[1] + c1 * M[5]) + c2 * M[9];
+    float dz = (c0 * M[2] + c1 * M[6]) + c2 * M[10];
+    float nrm = fmaxf(norm3(dx, dy, dz), 1e-12f);
+    dx /= nrm; dy /= nrm; dz /= nrm;
+    P.rays_d[3 * r] = dx; P.rays_d[3 * r + 1] = dy; P.rays_d[3 * r + 2] = dz;
+
+    float z1, z2;
+    const bool hit = ray_bbox(P.bounds, ox, oy, oz, dx, dy, dz, z1, z2);
     const float near = (hit && z1 > zn) ? z1 : zn; // src/model.py:1217-1220
     const float far = (hit && z2 < zf) ? z2 : zf;
     P.near[r] = near; P.far[r] = far; P.hit[r] = hit;
@@ -179,6 +201,9 @@ __global__ void composite_kernel(const float* __restrict__ rgba, const float* __
 // (element i of thread t at [i*64 + t]: conflict-free).
 constexpr int IM_BLOCK = 64;
 
+// MID = true: the reference's own call shape importance_sample(contrib[1:-1], z_mid, ...) (src/model.py:1304): `contrib` holds the
+// Sc-2 inner contributions and `z` the Sc-1 mid-points; only z_new / idx are produced.
+template <bool MID>
 __global__ __launch_bounds__(IM_BLOCK) void importance_merge_kernel(const float* __restrict__ contrib, const float* __restrict__ z,
                                                                     const float* __restrict__ u, const float* __restrict__ t_lin, int R,
                                                                     int Sc, int Sf, float* __restrict__ z_new, float* __restrict__ z_fine,
@@ -192,8 +217,8 @@ __global__ __launch_bounds__(IM_BLOCK) void importance_merge_kernel(const float*
     float* zmid = cdf + (size_t)(nb + 1) * IM_BLOCK; // nb + 1 entries
     float* smp = zmid + (size_t)(nb + 1) * IM_BLOCK; // Sf entries
     if (r >= R) return;
-    const float* c = contrib + (size_t)r * Sc;
-    const float* zr = z + (size_t)r * Sc;
+    const float* c = MID ? contrib + (size_t)r * nb - 1 : contrib + (size_t)r * Sc; // c[i + 1] = i-th inner contribution
+    const float* zr = MID ? z + (size_t)r * (nb + 1) : z + (size_t)r * Sc;
     // pdf = (contrib[1:-1] + 1e-5) / sum ; cdf = [0, cumsum(pdf)] (fp64 accumulate, fp32 values)
     double tot = 0.0;
     for (int i = 0; i < nb; ++i) tot += (double)(c[i + 1] + 1e-5f);
@@ -204,7 +229,7 @@ __global__ __launch_bounds__(IM_BLOCK) void importance_merge_kernel(const float*
         run += (double)((c[i + 1] + 1e-5f) / sum);
         cdf[(size_t)(i + 1) * IM_BLOCK] = (float)run;
     }
-    for (int i = 0; i < nb + 1; ++i) zmid[(size_t)i * IM_BLOCK] = 0.5f * (zr[i + 1] + zr[i]);
+    for (int i = 0; i < nb + 1; ++i) zmid[(size_t)i * IM_BLOCK] = MID ? zr[i] : 0.5f * (zr[i + 1] + zr[i]);
     bool sorted = true;
     float prev = -INFINITY;
     for (int k = 0; k < Sf; ++k) {
@@ -227,6 +252,7 @@ __global__ __launch_bounds__(IM_BLOCK) void importance_merge_kernel(const float*
         sorted = sorted && (s >= prev);
         prev = s;
     }
+    if (MID) return;
     // sort-merge (th.sort(th.cat([z, z_fine]))): stable merge of the two runs; the new samples are sorted first if
     // needed (random u in training, or a last-bit inversion), remembering where each merged sample came from.
     int32_t* srow = src + (size_t)r * (Sc + Sf);
@@ -259,18 +285,43 @@ __global__ __launch_bounds__(IM_BLOCK) void importance_merge_kernel(const float*
 
 } // namespace
 
+static void ray_setup_impl(const int32_t* pixels, int x0, int y0, int step_x, int step_y, int nx, int ny, int width, const float* invK_T,
+                           const float* RT, float znear, float zfar, const float* bounds, int S, const float* t_lin, const float* jitter,
+                           int64_t* index, float* rays_d, float* cam_pos, float* near, float* far, uint8_t* hit, float* z, void* stream);
+
 extern "C" int vanerf_ray_setup(int x0, int y0, int step_x, int step_y, int nx, int ny, int width, const float* invK_T, const float* RT,
                                 float znear, float zfar, const float* bounds, int S, const float* t_lin, const float* jitter,
                                 int64_t* index, float* rays_d, float* cam_pos, float* near, float* far, uint8_t* hit, float* z,
                                 void* stream)
 {
     return guarded([&] {
+        ray_setup_impl(nullptr, x0, y0, step_x, step_y, nx, ny, width, invK_T, RT, znear, zfar, bounds, S, t_lin, jitter, index, rays_d,
+                       cam_pos, near, far, hit, z, stream);
+    });
+}
+
+extern "C" int vanerf_ray_setup_pixels(const int32_t* pixels_xy, int n_rays, int width, const float* invK_T, const float* RT, float znear,
+                                       float zfar, const float* bounds, int S, const float* t_lin, const float* jitter, int64_t* index,
+                                       float* rays_d, float* cam_pos, float* near, float* far, uint8_t* hit, float* z, void* stream)
+{
+    return guarded([&] {
+        if (!pixels_xy) throw_error("vanerf_ray_setup_pixels: null pixel list");
+        ray_setup_impl(pixels_xy, 0, 0, 1, 1, n_rays, 1, width, invK_T, RT, znear, zfar, bounds, S, t_lin, jitter, index, rays_d, cam_pos,
+                       near, far, hit, z, stream);
+    });
+}
+
+static void ray_setup_impl(const int32_t* pixels, int x0, int y0, int step_x, int step_y, int nx, int ny, int width, const float* invK_T,
+                           const float* RT, float znear, float zfar, const float* bounds, int S, const float* t_lin, const float* jitter,
+                           int64_t* index, float* rays_d, float* cam_pos, float* near, float* far, uint8_t* hit, float* z, void* stream)
+{
+    {
         if (!invK_T || !RT || !bounds || !t_lin || !index || !rays_d || !cam_pos || !near || !far || !hit || !z)
             throw_error("vanerf_ray_setup: null argument");
         if (nx <= 0 || ny <= 0 || step_x <= 0 || step_y <= 0 || S < 2 || width <= 0)
             throw_error("vanerf_ray_setup: bad grid (nx=%d ny=%d step=%d,%d S=%d)", nx, ny, step_x, step_y, S);
         RayParams P;
-        P.x0 = x0; P.y0 = y0; P.step_x = step_x; P.step_y = step_y; P.nx = nx; P.ny = ny; P.width = width;
+        P.x0 = x0; P.y0 = y0; P.step_x = step_x; P.step_y = step_y; P.nx = nx; P.ny = ny; P.width = width; P.pixels = pixels;
         std::copy_n(invK_T, 9, P.invK_T);
         std::copy_n(RT, 12, P.RT);
         std::copy_n(bounds, 6, P.bounds);
@@ -279,7 +330,7 @@ extern "C" int vanerf_ray_setup(int x0, int y0, int step_x, int step_y, int nx, 
         const int R = nx * ny;
         hipLaunchKernelGGL(ray_setup_kernel, dim3((R + 255) / 256), dim3(256), 0, (hipStream_t)stream, P);
         HIP_CHECK(hipGetLastError());
-    });
+    }
 }
 
 extern "C" int vanerf_sample_points(const float* rays_d, const float* cam_pos, const float* z, int R, int S, float* pts, void* stream)
@@ -336,9 +387,40 @@ extern "C" int vanerf_importance_merge(const float* contrib, const float* z, con
         const size_t lds = (size_t)IM_BLOCK * sizeof(float) * (2 * (size_t)(Sc - 1) + 2 * (size_t)Sf);
         if (lds > 160 * 1024) throw_error("vanerf_importance_merge: %d + %d samples per ray exceed LDS", Sc, Sf);
         if (lds > 64 * 1024)
-            HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(importance_merge_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(importance_merge_kernel, dim3((R + IM_BLOCK - 1) / IM_BLOCK), dim3(IM_BLOCK), lds, (hipStream_t)stream,
+            HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(importance_merge_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(importance_merge_kernel<false>, dim3((R + IM_BLOCK - 1) / IM_BLOCK), dim3(IM_BLOCK), lds, (hipStream_t)stream,
                            contrib, z, u, t_lin, R, Sc, Sf, z_new, z_fine, src, idx);
+        HIP_CHECK(hipGetLastError());
+    });
+}
+
+extern "C" int vanerf_importance_sample(const float* contrib_inner, const float* z_mid, const float* u, const float* t_lin, int R, int n_bins,
+                                        int Sf, float* z_new, int32_t* idx, void* stream)
+{
+    return guarded([&] {
+        if (!contrib_inner || !z_mid || !z_new) throw_error("vanerf_importance_sample: null argument");
+        if (!u && !t_lin) throw_error("vanerf_importance_sample: need u (random) or t_lin (uniform)");
+        if (R <= 0 || n_bins < 1 || Sf < 1) throw_error("vanerf_importance_sample: R=%d bins=%d Sf=%d", R, n_bins, Sf);
+        const int Sc = n_bins + 2;
+        const size_t lds = (size_t)IM_BLOCK * sizeof(float) * (2 * (size_t)(Sc - 1) + 2 * (size_t)Sf);
+        if (lds > 160 * 1024) throw_error("vanerf_importance_sample: %d bins + %d samples per ray exceed LDS", n_bins, Sf);
+        if (lds > 64 * 1024)
+            HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(importance_merge_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(importance_merge_kernel<true>, dim3((R + IM_BLOCK - 1) / IM_BLOCK), dim3(IM_BLOCK), lds, (hipStream_t)stream,
+                           contrib_inner, z_mid, u, t_lin, R, Sc, Sf, z_new, nullptr, nullptr, idx);
+        HIP_CHECK(hipGetLastError());
+    });
+}
+
+extern "C" int vanerf_ray_bbox(const float* bounds, const float* orig, const float* dirs, int R, float* near, float* far, uint8_t* hit, void* stream)
+{
+    return guarded([&] {
+        if (!bounds || !orig || !dirs || !near || !far || !hit) throw_error("vanerf_ray_bbox: null argument");
+        if (R <= 0) throw_error("vanerf_ray_bbox: R=%d", R);
+        BboxParams B;
+        std::copy_n(bounds, 6, B.bounds);
+        std::copy_n(orig, 3, B.o);
+        hipLaunchKernelGGL(ray_bbox_kernel, dim3((R + 255) / 256), dim3(256), 0, (hipStream_t)stream, B, dirs, R, near, far, hit);
         HIP_CHECK(hipGetLastError());
     });
 }

@@ -1,0 +1,444 @@
+"""Drop-in mirror of the reference's renderer interface (class VANeRF, reference src/model.py:604-1570) on top of the
+HIP hot path.  Method names, argument order, dict layouts, returned keys/shapes, state_dict key names and assertion
+behaviour follow the reference so that `VANeRFLightningModule` (src/model.py:42-602), train.py --run_val and
+render_dynamic.py can call it unchanged; INTEGRATION.md shows the two-line change on the reference side.
+
+What runs where
+  * per-ray / per-sample work (a1-a19 of SURVEY.md section 8): libvanerf_hip.so through vanerf_amd/renderer.py;
+  * per-frame work (image encoders, vertex un-projection, TexVisFusion's global vertex feature): PyTorch-ROCm;
+  * n_views == 1 and batch == 1, as in both shipped configs (the non-spconv reference path is structurally single-view:
+    src/networks.py:86,94; render_pifu_nerf hard-codes n_views = 1, src/model.py:1044).
+
+Not differentiable: the fused forward has no backward yet (SURVEY.md section 8 row f-4 "next"); `forward()` therefore serves
+validation / inference-time use, and raises if called with autograd enabled on parameters that require grad.
+"""
+import copy
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as thf
+
+from . import renderer as R
+
+NUM_V = 779
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# parameter containers with the reference's module tree (=> identical state_dict keys)
+# ------------------------------------------------------------------------------------------------------------------
+def _conv1(i, o):
+    return nn.Conv1d(i, o, 1, padding=0, bias=False)
+
+
+class GeoVisFusion(nn.Module):
+    """Parameters of src/networks.py:43-73 (forward runs inside the HIP kernel)."""
+
+    def __init__(self):
+        super().__init__()
+        self.fconv_at = nn.Sequential(_conv1(196, 10), nn.ReLU(True), _conv1(10, 3), nn.Sigmoid())
+        self.fconv_ated = nn.Sequential(_conv1(196, 64), nn.ReLU(True), _conv1(64, 64))
+        self.fconv_at1 = nn.Sequential(_conv1(28, 10), nn.ReLU(True), _conv1(10, 3), nn.Sigmoid())
+        self.fconv_ated1 = nn.Sequential(_conv1(28, 8), nn.ReLU(True), _conv1(8, 8))
+
+
+class TexVisFusion(nn.Module):
+    """Parameters of src/networks.py:219-266; the per-frame stack (fconv3, fconv4, fconv_gt) runs in renderer.py."""
+
+    def __init__(self, q_feat_in=96, q_feat_out=40):
+        super().__init__()
+        self.fconv = nn.Sequential(_conv1(q_feat_in, q_feat_in), nn.ReLU(True), _conv1(q_feat_in, q_feat_out))
+        self.fconv_at = nn.Sequential(_conv1(q_feat_in, q_feat_in), nn.ReLU(True), _conv1(q_feat_in, 6), nn.Sigmoid())
+        self.fconv_gt = nn.Sequential(nn.Conv1d(42, NUM_V, 3, padding=1, bias=False), nn.LayerNorm(18, 1e-6), nn.ReLU(True),
+                                      nn.Conv1d(NUM_V, NUM_V * 2, 3, padding=1, bias=False), nn.LayerNorm(18, 1e-6), nn.ReLU(True))
+        self.fconv3 = nn.Sequential(nn.Conv2d(8, 21, 3, padding=1, bias=False), nn.LayerNorm([64, 64], 1e-6), nn.ReLU(True),
+                                    nn.Conv2d(21, 42, 3, padding=1, bias=False), nn.LayerNorm([64, 64], 1e-6), nn.ReLU(True),
+                                    nn.AdaptiveAvgPool2d(3))
+        self.fconv4 = nn.Sequential(nn.Conv2d(3, 21, 3, padding=1, bias=False), nn.LayerNorm([256, 256], 1e-6), nn.ReLU(True),
+                                    nn.Conv2d(21, 42, 3, padding=1, bias=False), nn.LayerNorm([256, 256], 1e-6), nn.ReLU(True),
+                                    nn.AdaptiveAvgPool2d(3))
+
+
+class _Linear(nn.Module):
+    """src/utils.py:670-685: `.linear` is a (weight-normed) nn.Linear -> keys linear.{weight_g,weight_v,bias} / linear.{weight,bias}."""
+
+    def __init__(self, n_in, n_out, wn):
+        super().__init__()
+        self.linear = nn.utils.weight_norm(nn.Linear(n_in, n_out)) if wn else nn.Linear(n_in, n_out)
+
+
+class _MLP(nn.Module):
+    def __init__(self, dims_in, dims_out, norm):
+        super().__init__()
+        n = len(dims_in)
+        self.layers = nn.ModuleList([_Linear(i, o, norm == "weight" and k != n - 1) for k, (i, o) in enumerate(zip(dims_in, dims_out))])
+
+
+class MLPUNetFusion(nn.Module):
+    """Parameters of src/utils.py:609-649 (layers1 = MLPUNet with skip concatenation, layers2 = MLP)."""
+
+    def __init__(self, n_dims1, n_dims2, skip_dims, skip_layers, norm="weight", **kwargs):
+        super().__init__()
+        skip = dict(zip(skip_layers, skip_dims))
+        ins1 = [n_dims1[i] + skip.get(i, 0) for i in range(len(n_dims1) - 1)]
+        self.layers1 = _MLP(ins1, n_dims1[1:], norm)
+        self.layers2 = _MLP(n_dims2[:-1], n_dims2[1:], norm)
+
+
+class IBRRenderingHead(nn.Module):
+    """Parameters of src/model.py:1572-1591.  At n_views == 1 its output is exactly rgb_feat[..., :3] (softmax over a single
+    view, src/model.py:1613, 1635), so the HIP path never evaluates it; the parameters exist for checkpoint compatibility."""
+
+    def __init__(self, in_channels=32 + 5, **kwargs):
+        super().__init__()
+        c = in_channels + 3
+        self.ani_al = nn.Parameter(torch.tensor(0.2))
+        self.ray_encoder = nn.Sequential(nn.Linear(4, 16), nn.ELU(inplace=True), nn.Linear(16, c), nn.ELU(inplace=True))
+        self.base_layer = nn.Sequential(nn.Linear(c * 3, 64), nn.ELU(inplace=True), nn.Linear(64, 32), nn.ELU(inplace=True))
+        self.vis_layer1 = nn.Sequential(nn.Linear(32, 32), nn.ELU(inplace=True), nn.Linear(32, 33), nn.ELU(inplace=True))
+        self.vis_layer2 = nn.Sequential(nn.Linear(32, 32), nn.ELU(inplace=True), nn.Linear(32, 1), nn.Sigmoid())
+        self.out_layer = nn.Sequential(nn.Linear(37, 16), nn.ELU(inplace=True), nn.Linear(16, 8), nn.ELU(inplace=True), nn.Linear(8, 1))
+
+
+class SpatialEncoder(nn.Module):
+    """Config holder of src/spatial.py (the 'rel_z_decay' encoding itself is fused into the HIP kernel)."""
+
+    def __init__(self, sp_level, sp_type, scale, n_kpt, **kwargs):
+        super().__init__()
+        self.sp_type, self.sp_level, self.n_kpt, self.scale, self.kwargs = sp_type, sp_level, n_kpt, scale, kwargs
+        self.register_buffer("center", torch.Tensor(kwargs.get("center", [0.0, 0.0, 0.0])).float())
+
+    def get_dim(self):
+        if self.sp_type != "rel_z_decay":
+            raise NotImplementedError(f"sp_type {self.sp_type!r}: only 'rel_z_decay' (both shipped configs) is implemented")
+        return (1 + 2 * self.sp_level) * self.n_kpt
+
+
+# ------------------------------------------------------------------------------------------------------------------
+class VANeRF(nn.Module):
+    def __init__(self, cfg, geo_encoder=None, tex_encoder=None):
+        super().__init__()
+        model_cfg = cfg["models"]["VANeRF"]
+        if model_cfg.get("sp_conv"):
+            raise NotImplementedError("sp_conv=True (sparse-voxel fusion) is outside the hot path; both shipped configs set it to false")
+        self.train_out_h = model_cfg.get("train_out_h", 64)
+        self.train_out_w = model_cfg.get("train_out_w", 64)
+        self.disable_fg_mask = model_cfg.get("disable_fg_mask", False)
+        if self.disable_fg_mask:
+            raise NotImplementedError("disable_fg_mask is not used by the shipped configs")
+        self.nkpt_r, self.nkpt_l = 21, 21
+        self.sigmoid_beta = nn.Parameter(0.1 * torch.ones(1))
+        self.geo_vis_fusion = GeoVisFusion()
+        self.tex_vis_fusion = TexVisFusion()
+        sp_encoder = SpatialEncoder(**model_cfg["sp_args"])
+        mlp_geo_args = copy.deepcopy(model_cfg["mlp_geo_args"])
+        mlp_geo_args["n_dims1"][0] = sp_encoder.get_dim()
+        if (mlp_geo_args["n_dims1"], mlp_geo_args["n_dims2"], mlp_geo_args["skip_dims"], mlp_geo_args["skip_layers"]) != \
+                ([294, 128, 128, 120, 64], [128, 64, 64, 2], [64, 8], [0, 2]) or mlp_geo_args.get("pool_types") != ["mean", "var"]:
+            raise NotImplementedError("the HIP kernel is specialised on the shipped mlp_geo_args (configs/vanerf.json:62-90)")
+        self.mlp_geo = MLPUNetFusion(**mlp_geo_args)
+        self.mlp_tex = IBRRenderingHead(**model_cfg["mlp_tex_args"]["args"])
+        self.ibr_compress_gfeat = nn.Linear(model_cfg["mlp_tex_args"]["gcompress"]["in_ch"], model_cfg["mlp_tex_args"]["gcompress"]["out_ch"])
+        if geo_encoder is None or tex_encoder is None:
+            from .encoders import HGFilterV2, ResBlkEncoder
+            geo_encoder = geo_encoder or HGFilterV2(**model_cfg["geo_args"])
+            tex_encoder = tex_encoder or ResBlkEncoder(**model_cfg["tex_args"])
+        self.geo_encoder, self.tex_encoder = geo_encoder, tex_encoder
+        self.sp_encoder = sp_encoder
+        self.sp_encoder_r = SpatialEncoder(**model_cfg["sp_args"])
+        self.sp_encoder_l = SpatialEncoder(**model_cfg["sp_args"])
+        self.sp_encoder_postfusion = None
+        self.ds_geo = model_cfg.get("ds_geo", 0)
+        self.ds_tex = model_cfg.get("ds_tex", 0)
+        self.v_level = model_cfg.get("v_level", 0)
+        self.dr_level = model_cfg.get("dr_level", 5)
+        self.feat_geo = None
+        self.feat_tex = None
+        self.kwargs = model_cfg
+        self.disable_bg = True
+        self._packed = None  # (version key, PackedWeights)
+        self._frame_cache = None
+
+    # ---- image features (src/model.py:700-746) ---------------------------------------------------------------------
+    def attach_im_feat(self, im, return_val=False):
+        if return_val:
+            out = {"feat_geo": self.attach_geo_feat(im, return_val)}
+            feat_tex = self.attach_tex_feat(im, return_val)
+            if feat_tex is not None:
+                out["feat_tex"] = feat_tex
+            return out
+        self.attach_geo_feat(im, return_val)
+        self.attach_tex_feat(im, return_val)
+
+    def attach_geo_feat(self, im, return_val=False):
+        if not return_val:
+            self.im = im.clone()
+        if len(im.shape) == 5:
+            im = im.view(-1, *im.shape[2:])
+        for _ in range(self.ds_geo):
+            im = thf.avg_pool2d(im, 2, stride=2)
+        self.feat_geo = self.geo_encoder(2.0 * im - 1.0)
+        if return_val:
+            return self.feat_geo
+
+    def attach_tex_feat(self, im, return_val=False):
+        if self.tex_encoder is None:
+            return None
+        if len(im.shape) == 5:
+            im = im.view(-1, *im.shape[2:])
+        for _ in range(self.ds_tex):
+            im = thf.avg_pool2d(im, 2, stride=2)
+        self.feat_tex = self.tex_encoder(2.0 * im - 1.0)
+        if return_val:
+            return self.feat_tex
+
+    def detach_im_feat(self):
+        self.feat_geo = None
+        self.feat_tex = None
+
+    # ---- HIP-side state ----------------------------------------------------------------------------------------------
+    def _hot_state(self):
+        return {k: v for k, v in self.state_dict().items() if not k.startswith(("geo_encoder.", "tex_encoder."))}
+
+    def packed_weights(self):
+        """MFMA-fragment copy of the per-sample weights, re-packed whenever a parameter changed (training steps, load_state_dict)."""
+        sd = self._hot_state()
+        key = tuple((k, v._version, v.data_ptr()) for k, v in sd.items() if k.startswith(("geo_vis_fusion.", "mlp_geo.", "ibr_compress_gfeat.",
+                                                                                         "tex_vis_fusion.fconv.", "tex_vis_fusion.fconv_at.", "sigmoid_beta")))
+        if self._packed is None or self._packed[0] != key:
+            self._packed = (key, R.PackedWeights(sd))
+        return self._packed[1]
+
+    def frame_data(self, img_in, cam_in, targets, feat_geo, feat_tex, sp_data, fg_mask):
+        """Per-source-frame device data (vertex features, visibility, acceleration structure); cached on the identity of its inputs
+        because render_pifu_nerf / render_novel_views call batch_render_pifu_nerf many times per source frame."""
+        key = (img_in.data_ptr(), feat_geo[0].data_ptr(), feat_tex.data_ptr(), targets["vert_world"].data_ptr(), cam_in["KRT"].data_ptr(),
+               sp_data["kpt3d"].data_ptr(), fg_mask.data_ptr(), tuple(p._version for p in self.tex_vis_fusion.parameters()))
+        if self._frame_cache is None or self._frame_cache[0] != key:
+            sd = {"tex_vis_fusion." + k: v for k, v in self.tex_vis_fusion.state_dict().items()}
+            fd = R.FrameData(sd, img_in, feat_geo, feat_tex, fg_mask, cam_in, targets, sp_data, self.kwargs["sp_args"])
+            self._frame_cache = (key, fd)
+        return self._frame_cache[1]
+
+    # ---- per-sample query (src/model.py:748-877) ---------------------------------------------------------------------
+    def query(self, pts, cam, hand_type, targets, feat_geo=None, feat_tex=None, vert=None, vert_vis=None, query_vis=None, query_sdf=None,
+              closest_face=None, n_views=1, sp_data={}, tx_data={}, view=None, n_pts_samples=-1, **kwargs):
+        """(B=1, N, 3) -> out (1, N, 5) = [sdf_pred, rad, r, g, b], valid (1, N, 1) bool.  `vert_vis` / `closest_face` / `view` are accepted for
+        signature compatibility: visibility is recomputed per frame by the same rasteriser and `view` only feeds the value-dead IBR head."""
+        assert n_views == 1 and pts.shape[0] == 1, "the non-spconv path is single-view (src/networks.py:86,94)"
+        feat_geo = self.feat_geo if feat_geo is None else feat_geo
+        feat_tex = self.feat_tex if feat_tex is None else feat_tex
+        fd = self.frame_data(tx_data["img"], cam, targets, feat_geo, feat_tex, sp_data, kwargs["src_foreground_mask"])
+        p = pts[0].contiguous().float()
+        if query_sdf is None or query_vis is None:
+            q_sdf, q_vis, knn = R.mesh_query_accel(fd.accel, fd.verts3, fd.faces, fd.vert_vis, p)
+        else:
+            q_sdf, q_vis = query_sdf.reshape(-1).float().contiguous(), query_vis.reshape(-1).to(torch.uint8).contiguous()
+            knn = R.knn1(fd.verts4, p)
+        out, valid = R.query_samples(self.packed_weights(), fd, p, q_sdf, q_vis, knn, want_valid=True, raw=True)
+        sp_data.update({"n_view": n_views, "pts": pts, "v": pts})  # the reference mutates sp_data in place (model.py:833-834)
+        sp_data.update(cam)
+        return out[None], valid.bool()[None, :, None]
+
+    def sdf_activation(self, input):
+        self.sigmoid_beta.data.clamp_(min=2e-3)  # in-place clamp of the parameter (src/model.py:880)
+        return torch.sigmoid(input / self.sigmoid_beta) / self.sigmoid_beta
+
+    @staticmethod
+    def rgba2out(self, rgba, z, vert_sdf):
+        """src/model.py:1464-1494 -> color (B,R,3), depth, alpha (B,R), contrib (B,R,S), sdf (B,R)."""
+        self.sigmoid_beta.data.clamp_(min=2e-3)
+        B, Rn, S = z.shape
+        c, d, a, con, s = R.composite(rgba.reshape(B * Rn, S, 5).float().contiguous(), z.reshape(B * Rn, S).float().contiguous(),
+                                      vert_sdf.reshape(B * Rn, S).float().contiguous(), float(self.sigmoid_beta.detach()))
+        return c.view(B, Rn, 3), d.view(B, Rn), a.view(B, Rn), con.view(B, Rn, S), s.view(B, Rn)
+
+    @staticmethod
+    def importance_sample(contrib, z, sample_per_ray, uniform=False):
+        """src/model.py:1424-1462: contrib (B,N,D-2), z (B,N,D-1) mid-points -> (B,N,sample_per_ray)."""
+        assert contrib.shape[-1] == z.shape[-1] - 1
+        B, N, D2 = contrib.shape
+        u = None if uniform else torch.rand(B * N, sample_per_ray, device=contrib.device)  # th.rand(...), src/model.py:1443
+        out = R.importance_from_midpoints(contrib.reshape(B * N, D2).float().contiguous(), z.reshape(B * N, D2 + 1).float().contiguous(),
+                                          sample_per_ray, u)
+        return out.view(B, N, sample_per_ray)
+
+    @staticmethod
+    def ray_bbox_intersection(bounds, orig, direct, boffset=(-0.01, 0.01)):
+        """src/model.py:1496-1570: bounds (B,2,3), orig (B,1,3), direct (B,N,3) -> near, far (B,N,1), hit (B,N,1) bool."""
+        assert tuple(boffset) == (-0.01, 0.01), "the kernel hard-codes the reference's default offsets"
+        outs = [R.ray_bbox(bounds[b], orig[b, 0], direct[b].contiguous().float()) for b in range(bounds.shape[0])]
+        near, far, hit = (torch.stack([o[i] for o in outs], 0)[..., None] for i in range(3))
+        return near, far, hit.bool()
+
+    # ---- whole passes ------------------------------------------------------------------------------------------------
+    @staticmethod
+    def batch_render_pifu_nerf(net, img_in, cam_in, hand_type, targets, n_views, cam_tar, level=2, stride=0, tar_img=None, feat_geo=None,
+                               feat_tex=None, mano_vert_world=None, sp_data={}, objcenter=None, **config):
+        """src/model.py:1102-1422.  Same config keys (sample_per_ray_c/f, fine, uniform, rand_noise_std, src_foreground_mask, bounds, msk)."""
+        batch_size = cam_tar["K"].shape[0]
+        assert batch_size == 1 and n_views == 1, "val_batch_size = 1 and one source view (configs/vanerf.json:24; src/model.py:1044)"
+        Sc = config.get("sample_per_ray_c", 64)
+        Sf = config.get("sample_per_ray_f", 64)
+        fine = config.get("fine", False)
+        uniform = config.get("uniform", False)
+        if config.get("separate_cf", False):
+            raise NotImplementedError("separate_cf is not used by the shipped configs")
+        noise_std = config.get("rand_noise_std", 0.0) if net.training else config.get("rand_noise_std", 0.0)
+        if feat_geo is None:
+            feat_geo = net.attach_geo_feat(img_in, return_val=True)
+        if feat_tex is None:
+            feat_tex = net.attach_tex_feat(img_in, return_val=True)
+        width = cam_tar.get("width", cam_in["width"])
+        height = cam_tar.get("height", cam_in["height"])
+        st = 2 ** (level - 1)
+        assert width % st == 0 and height % st == 0
+        if isinstance(stride, int):
+            assert stride < st
+            off = (stride, stride)
+        elif isinstance(stride, torch.Tensor):
+            assert stride.max().item() < st
+            off = tuple(int(v) for v in stride.reshape(-1, 2)[0].tolist())
+        else:
+            raise NotImplementedError("unsupported stride type")
+        dev = img_in.device
+        cam_t = dict(cam_tar, width=width, height=height, znear=cam_tar.get("znear", cam_in["znear"]), zfar=cam_tar.get("zfar", cam_in["zfar"]))
+        fd = net.frame_data(img_in, cam_in, targets, feat_geo, feat_tex, sp_data, config["src_foreground_mask"])
+        pixels = None
+        if net.training and "msk" in config:  # 64x64 window around a random mask pixel, clamped (src/model.py:1172-1189)
+            out_h, out_w = net.train_out_h, net.train_out_w
+            msk = config["msk"][0].squeeze()
+            coords = torch.stack(torch.where(msk)[::-1], -1)
+            centre = coords[np.random.randint(0, coords.shape[0], 1)] if coords.shape[0] > 0 else torch.zeros((1, 2), device=msk.device)
+            yg, xg = torch.meshgrid(torch.arange(0, out_h, device=dev), torch.arange(0, out_w, device=dev), indexing="ij")
+            grids = torch.stack([xg, yg], -1).view(-1, 2) + (centre.to(dev) - out_h // 2)
+            pixels = grids.clamp(0, min(width - 1, height - 1)).to(torch.int32).contiguous()
+            nx, ny, x0, y0, step = out_w * out_h, 1, 0, 0, 1
+        else:
+            out_w, out_h = width // st, height // st
+            nx, ny, x0, y0, step = out_w, out_h, off[0], off[1], st
+        Rn = out_w * out_h
+        jitter = None if uniform else torch.rand(Rn, Sc, device=dev)          # th.rand_like(z), src/model.py:1229
+        u = None if uniform else torch.rand(Rn, Sf, device=dev)                # th.rand(...), src/model.py:1443
+        o = R.render_pass(net.packed_weights(), fd, cam_t, config["bounds"], x0, y0, step, nx, ny, Sc, Sf, fine=fine, jitter=jitter, u=u,
+                          noise_std=float(noise_std), pixels=pixels)
+        out = {"tex_fg": o["color"].view(1, out_h, out_w, 3).permute(0, 3, 1, 2), "depth": o["depth"].view(1, out_h, out_w),
+               "alpha": o["alpha"].view(1, out_h, out_w)}
+        if fine:
+            out.update({"tex_fg_fine": o["color_fine"].view(1, out_h, out_w, 3).permute(0, 3, 1, 2), "depth_fine": o["depth_fine"].view(1, out_h, out_w),
+                        "alpha_fine": o["alpha_fine"].view(1, out_h, out_w), "sdf": o["sdf"].view(1, out_h, out_w)})
+        index = o["index"][None]
+
+        def gather(t, ch):  # GT gathers at `index` (src/model.py:1361-1418); the reference indexes source-sized tensors with target
+            flat = t.reshape(t.shape[0], ch, -1)  # pixel indices and fails for targets larger than the source -- guarded here
+            if int(index.max()) >= flat.shape[-1]:
+                return None
+            return torch.gather(flat, 2, index[:, None].expand(-1, ch, -1)).view(t.shape[0], ch, out_h, out_w)
+
+        if tar_img is not None:
+            g = gather(tar_img, 3)
+            if g is not None:
+                out["tar_img"] = g
+            if "msk" in config:
+                g = gather(config["msk"].reshape(1, 1, -1), 1)
+                if g is not None:
+                    out["tar_alpha"] = g.float()
+        # render_vis (pytorch3d soft rasteriser, discriminator supervision only) is out of scope: zeros of the reference's shape
+        out["vis_img_all"] = torch.zeros(1, 1, 256, 256, device=dev)
+        for key, t, ch in (("vis_img", out["vis_img_all"], 1), ("input_mask", config["src_foreground_mask"].reshape(1, 1, *config["src_foreground_mask"].shape[-2:]), 1),
+                           ("img_in", img_in, 3)):
+            g = gather(t, ch)
+            if g is not None:
+                out[key] = g
+        for key in ("input_densepose", "tar_densepose"):
+            if key in targets:
+                g = gather(targets[key], 3)
+                if g is not None:
+                    out[key] = g
+        out["vert_vis"] = fd.vert_vis[None, :, None]
+        return out
+
+    @staticmethod
+    def render_pifu_nerf(self, net, img_in, cam_in, hand_type, targets, cam_tar, level=5, sp_data={}, bkg_emb=None, camcenter=None, objcenter=None,
+                         tar_img=None, **config):
+        """src/model.py:1026-1100.  The reference renders stride^2 pixel-interleaved passes and pixel_shuffles them because its unfused
+        intermediates do not fit; rays are independent, so ONE full-resolution launch (level 1) yields the same image."""
+        feat_geo = net.attach_geo_feat(img_in, return_val=True)
+        feat_tex = net.attach_tex_feat(img_in, return_val=True)
+        out = net.batch_render_pifu_nerf(net, img_in, cam_in, hand_type, targets, 1, cam_tar, 1, 0, tar_img, feat_geo, feat_tex, None, sp_data,
+                                         objcenter, **config)
+        if "input_densepose" in out and self is not None and hasattr(self, "discriminator"):
+            rendered = out["tex_fg_fine"].clamp(min=0.0, max=1.0)
+            _, out["fake_vis_pred"] = self.discriminator(out["img_in"], out["input_densepose"], out["tar_densepose"], rendered.detach())
+            _, out["real_vis_pred"] = self.discriminator(out["img_in"], out["input_densepose"], out["tar_densepose"], out["tar_img"])
+        ret = {}
+        for k, v in out.items():
+            if v is None or len(v.shape) < 3:
+                continue
+            ret[k] = v[0] if len(v.shape) == 4 else v  # (C,H,W); 3-D tensors (B,H,W) already read as (1,H,W)
+        vert3d = targets["vert_world"]
+        vimg = vert3d @ cam_tar["KRT"][:, :3, :3].transpose(1, 2) + cam_tar["KRT"][:, :3, 3][:, None]
+        ret["vert_xy"] = vimg[..., :2] / (vimg[..., 2:3] + 1e-8)
+        ret["vert_vis"] = out["vert_vis"]
+        return ret
+
+    def forward(self, im, cam, hand_type, targets, data, bbox, n_views=1, sp_data={}, dr_data=None, **kwargs):
+        """src/model.py:959-1024 (losses are the caller's: compute_error / VGG are outside the hot path).  Returns
+        dict(loss=None, err_dict={}, out={'nerf': out_nerf}) with the reference's out_nerf keys."""
+        assert len(im.shape) == 4 and len(cam["KRT"].shape) == 3
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()) and self.training:
+            raise NotImplementedError("the fused HIP forward has no backward yet (SURVEY.md section 8, row f-4); call under torch.no_grad()")
+        dr_kwargs = self.kwargs.get("dr_kwargs", {})
+        feat_geo = self.attach_geo_feat(im, return_val=True)
+        feat_tex = self.attach_tex_feat(im, return_val=True)
+        n_batch = im.shape[0] // n_views
+        stride = 0 if self.dr_level == 1 else torch.randint(high=(2 ** (self.dr_level - 1) - 1), size=(n_batch, 2))
+        out_nerf = self.batch_render_pifu_nerf(self, dr_data["img"], dr_data["cam"], hand_type, targets, n_views, dr_data["cam_tar"], self.dr_level,
+                                               stride, dr_data["tar"], feat_geo, feat_tex, None, sp_data, dr_data.get("objcenter", None),
+                                               msk=dr_data["msk"], src_foreground_mask=kwargs["src_foreground_mask"], bounds=kwargs["bounds"],
+                                               **dr_kwargs)
+        if self.disable_bg:
+            out_nerf["tex_bg"] = 0.0
+        out_nerf["tex"] = out_nerf["tex_cal"] = out_nerf["tex_fg"]
+        if "tex_fg_fine" in out_nerf:
+            out_nerf["tex_fine"] = out_nerf["tex_cal_fine"] = out_nerf["tex_fg_fine"]
+        return dict(loss=None, err_dict={}, out={"nerf": out_nerf})
+
+
+def get_360cameras(headpose, focal, trans, sc_factor, im_w, im_h, znear, zfar, n_frames=90):
+    """Orbit cameras of src/utils.py:63-134 (cv2.Rodrigues about the y axis written out; device follows `headpose`)."""
+    device = headpose.device
+    T_i = torch.eye(4, device=device)
+    T_i[:3, :4] = headpose[:3, :4]
+    T_i[:3, :3] = T_i[:3, :3].t()
+    T_i[:3, 3] = -T_i[:3, :3] @ T_i[:3, 3]
+    cams, theta0, theta1 = [], 0.0, 0.0
+    for idx in range(n_frames):
+        c, s = math.cos(theta0), math.sin(theta0)
+        dR = torch.tensor([[c, 0.0, s], [0.0, 1.0, 0.0], [-s, 0.0, c]], dtype=torch.float32)  # Rodrigues((0, theta0, 0))
+        extrin_tar = torch.eye(4)
+        intrin_tar = torch.eye(4)
+        extrin_tar[:3, :3] = dR
+        extrin_tar[:3, 3] = torch.tensor([0.0, 0.0, trans])
+        intrin_tar[:3, :3] = torch.tensor([[focal, 0, im_w / 2], [0, focal, im_h / 2], [0, 0, 1]], dtype=torch.float32)
+        extrinsic = torch.matmul(extrin_tar.to(device), T_i).clone()
+        extrinsic[:3, 3] *= sc_factor
+        i = idx + 0.0001
+        d = 5.0 * math.pi * 0.1 / n_frames
+        if 0 <= i <= n_frames / 10:
+            theta0 += d; theta1 += d
+        elif n_frames / 10 < i < n_frames * 3 / 10:
+            theta0 -= d
+        elif n_frames * 3 / 10 < i < n_frames * 5 / 10:
+            theta1 -= d
+        elif n_frames * 5 / 10 < i < n_frames * 7 / 10:
+            theta0 += d
+        elif n_frames * 7 / 10 < i < n_frames * 9 / 10:
+            theta1 += d
+        elif i >= n_frames * 9 / 10:
+            theta0 -= d; theta1 -= d
+        theta0 += 2.0 * math.pi / n_frames
+        cams.append({"w2cs": extrinsic.to(device), "c2ws": torch.inverse(extrinsic).to(device), "intrinsics": intrin_tar.to(device).unsqueeze(0),
+                     "im_w": im_w, "im_h": im_h, "znear": znear, "zfar": zfar})
+    return cams

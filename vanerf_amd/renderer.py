@@ -336,13 +336,13 @@ def knn1(verts4, pts):
     return idx
 
 
-def query_samples(weights, frame, pts, query_sdf, query_vis, knn_idx, noise=None, want_valid=False):
+def query_samples(weights, frame, pts, query_sdf, query_vis, knn_idx, noise=None, want_valid=False, raw=False):
     """VANeRF.query + eval_func (src/model.py:748-957, 1140-1160): (N,3),(N,),(N,)u8,(N,)i32 -> (N,5) [alpha, sdf, r, g, b]."""
     n = pts.shape[0]
     out = torch.empty(n, 5, dtype=torch.float32, device=pts.device)
     valid = torch.empty(n, dtype=torch.uint8, device=pts.device) if want_valid else None
     check(lib.vanerf_query_samples(weights.handle, byref(frame.c), _ptr(pts, torch.float32), _ptr(query_sdf, torch.float32),
-                                   _ptr(query_vis, torch.uint8), _ptr(knn_idx, torch.int32), _ptr(noise, torch.float32), n, _ptr(out),
+                                   _ptr(query_vis, torch.uint8), _ptr(knn_idx, torch.int32), _ptr(noise, torch.float32), int(bool(raw)), n, _ptr(out),
                                    _ptr(valid), _stream()))
     return (out, valid) if want_valid else out
 
@@ -389,8 +389,33 @@ def importance_merge(contrib, z, sample_per_ray, u=None, want_idx=False):
     return (z_new, z_fine, src, idx) if want_idx else (z_new, z_fine, src)
 
 
-def ray_setup(cam_tar, bounds, x0, y0, step, nx, ny, S, jitter=None, device=None, y_step=None):
-    """Pixel grid + rays + bbox clip + coarse depths (src/model.py:1191-1238, 1496-1570)."""
+def importance_from_midpoints(contrib_inner, z_mid, sample_per_ray, u=None, want_idx=False):
+    """importance_sample in the reference's call shape (src/model.py:1304): contrib[..., 1:-1] (R,D-2), z_mid (R,D-1) -> (R,Sf)."""
+    Rn, nb = contrib_inner.shape
+    assert z_mid.shape == (Rn, nb + 1)
+    dev = z_mid.device
+    Sf = int(sample_per_ray)
+    t_lin = torch.linspace(0.0, 1.0, steps=Sf).to(dev) if u is None else None
+    z_new = torch.empty(Rn, Sf, dtype=torch.float32, device=dev)
+    idx = torch.empty(Rn, Sf, dtype=torch.int32, device=dev) if want_idx else None
+    check(lib.vanerf_importance_sample(_ptr(contrib_inner, torch.float32), _ptr(z_mid, torch.float32), _ptr(u, torch.float32), _ptr(t_lin), Rn, nb, Sf,
+                                       _ptr(z_new), _ptr(idx), _stream()))
+    return (z_new, idx) if want_idx else z_new
+
+
+def ray_bbox(bounds, orig, dirs):
+    """ray_bbox_intersection (src/model.py:1496-1570): bounds (2,3), orig (3,), dirs (R,3) device -> near, far (R,), hit (R,) uint8."""
+    Rn = dirs.shape[0]
+    near, far = torch.empty(Rn, dtype=torch.float32, device=dirs.device), torch.empty(Rn, dtype=torch.float32, device=dirs.device)
+    hit = torch.empty(Rn, dtype=torch.uint8, device=dirs.device)
+    check(lib.vanerf_ray_bbox(_farr(bounds.detach().reshape(-1).tolist(), 6), _farr(orig.detach().reshape(-1).tolist(), 3), _ptr(dirs, torch.float32),
+                              Rn, _ptr(near), _ptr(far), _ptr(hit), _stream()))
+    return near, far, hit
+
+
+def ray_setup(cam_tar, bounds, x0, y0, step, nx, ny, S, jitter=None, device=None, y_step=None, pixels=None):
+    """Pixel grid + rays + bbox clip + coarse depths (src/model.py:1191-1238, 1496-1570).
+    pixels: optional explicit (R,2) int32 device tensor of (x, y) (training patches); then nx*ny must equal R."""
     dev = device or bounds.device
     K = cam_tar["K"].detach().to("cpu", torch.float32)
     RT = cam_tar["RT"].detach().to("cpu", torch.float32)
@@ -403,10 +428,14 @@ def ray_setup(cam_tar, bounds, x0, y0, step, nx, ny, S, jitter=None, device=None
     hit = torch.empty(R, dtype=torch.uint8, device=dev)
     z = torch.empty(R, S, dtype=torch.float32, device=dev)
     t_lin = torch.linspace(0.0, 1.0, steps=S).to(dev)
-    check(lib.vanerf_ray_setup(int(x0), int(y0), int(step), int(y_step or step), int(nx), int(ny), int(cam_tar["width"]), _farr(inv_K_T.reshape(-1).tolist(), 9),
-                               _farr(RT[0, :3, :4].reshape(-1).tolist(), 12), float(cam_tar["znear"]), float(cam_tar["zfar"]),
-                               _farr(bounds.detach().reshape(-1).tolist(), 6), int(S), _ptr(t_lin), _ptr(jitter, torch.float32),
-                               _ptr(index), _ptr(rays_d), _ptr(cam_pos), _ptr(near), _ptr(far), _ptr(hit), _ptr(z), _stream()))
+    cam_args = (_farr(inv_K_T.reshape(-1).tolist(), 9), _farr(RT[0, :3, :4].reshape(-1).tolist(), 12), float(cam_tar["znear"]),
+                float(cam_tar["zfar"]), _farr(bounds.detach().reshape(-1).tolist(), 6), int(S), _ptr(t_lin), _ptr(jitter, torch.float32),
+                _ptr(index), _ptr(rays_d), _ptr(cam_pos), _ptr(near), _ptr(far), _ptr(hit), _ptr(z), _stream())
+    if pixels is not None:
+        assert pixels.shape == (R, 2)
+        check(lib.vanerf_ray_setup_pixels(_ptr(pixels, torch.int32), R, int(cam_tar["width"]), *cam_args))
+    else:
+        check(lib.vanerf_ray_setup(int(x0), int(y0), int(step), int(y_step or step), int(nx), int(ny), int(cam_tar["width"]), *cam_args))
     return dict(index=index, rays_d=rays_d, cam_pos=cam_pos, near=near, far=far, hit=hit, z=z)
 
 
@@ -421,7 +450,8 @@ def sample_points(rays_d, cam_pos, z):
 # one pass: rays -> coarse march -> importance -> fine march (src/model.py:1102-1360)
 # ------------------------------------------------------------------------------------------------
 def render_pass(weights, frame, cam_tar, bounds, x0, y0, step, nx, ny, sample_per_ray_c=64, sample_per_ray_f=64, fine=True,
-                jitter=None, u=None, noise_std=0.0, generator=None, debug=False, kernel_events=None, y_step=None, reuse_coarse=True):
+                jitter=None, u=None, noise_std=0.0, generator=None, debug=False, kernel_events=None, y_step=None, reuse_coarse=True,
+                pixels=None):
     """Returns flat per-ray tensors: color/depth/alpha (coarse), color_fine/depth_fine/alpha_fine/sdf (fine), index, z, z_fine.
 
     reuse_coarse: the fine composite needs the networks at the Sc coarse and the Sf new depths of every ray.  The reference
@@ -430,7 +460,7 @@ def render_pass(weights, frame, cam_tar, bounds, x0, y0, step, nx, ny, sample_pe
     With per-sample noise (training, rand_noise_std > 0) the reference draws fresh noise for the re-evaluated coarse
     samples, so re-use is switched off there."""
     Sc, Sf = int(sample_per_ray_c), int(sample_per_ray_f)
-    rays = ray_setup(cam_tar, bounds, x0, y0, step, nx, ny, Sc, jitter=jitter, device=frame.verts3.device, y_step=y_step)
+    rays = ray_setup(cam_tar, bounds, x0, y0, step, nx, ny, Sc, jitter=jitter, device=frame.verts3.device, y_step=y_step, pixels=pixels)
     R = nx * ny
     if noise_std > 0.0:
         reuse_coarse = False
