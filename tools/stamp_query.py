@@ -31,7 +31,16 @@ stamps = torch.zeros(nw.value, 12, dtype=torch.int64, device="cuda")
 assert fn(*args(ctypes.c_void_p(stamps.data_ptr()))) == 0
 torch.cuda.synchronize()
 s = stamps.cpu().double()
+rt = s[:, 11].clone()
+s[:, 11] = 0
 tot = s.sum(1)
+print(f"in-kernel clock: {(tot / rt).median().item() * 100:.0f} MHz (s_memtime / s_memrealtime x 100 MHz)")
+import time
+t0 = time.perf_counter(); assert fn(*args(ctypes.c_void_p(stamps.data_ptr()))) == 0; torch.cuda.synchronize(); wall = time.perf_counter() - t0
+q = torch.quantile(tot, torch.tensor([0.0, 0.05, 0.5, 0.95, 1.0], dtype=torch.float64))
+print("per-wave total cycles min/5%/median/95%/max:", [f"{v:.3e}" for v in q.tolist()], f"wall {wall*1e3:.2f} ms = {wall*2.326e9:.3e} cycles")
+per_cu = tot.view(-1, 4).sum(1)
+print("per-block totals min/max:", f"{per_cu.min():.3e} {per_cu.max():.3e}")
 groups = (n + 31) // 32
 print(f"waves {nw.value}, groups/wave {groups / nw.value:.1f}, mean cycles/wave {tot.mean():.3e}, cycles per group per wave {tot.sum() / groups:.0f}")
 for k, name in enumerate(NAMES[:11]):

@@ -73,4 +73,8 @@ struct VanerfWeights {
     int mode = 0;
     float beta = 0.1f;
     int device = 0;
+    // work-queue heads of query_kernel (one per launch, used round robin; zeroed on the launch stream before each use)
+    static constexpr int N_QUEUES = 64;
+    unsigned* queues = nullptr;
+    unsigned next_queue = 0;
 };

@@ -51,4 +51,12 @@ struct LayerOffsets {
 
 constexpr unsigned layer_floats(int l) { return (unsigned)kT[l] * 64u * (unsigned)kNB[l]; }
 
+// Layers are packed back to back in enum order, so every offset is a compile-time constant (no SGPRs spent on a table).
+constexpr unsigned layer_offset(int l)
+{
+    unsigned o = 0;
+    for (int i = 0; i < l; ++i) o += layer_floats(i);
+    return o;
+}
+
 } // namespace vanerf

@@ -11,6 +11,7 @@
 //
 // Built with -ffp-contract=off: the integer-valued outputs (1-NN index) depend on fp32 compare
 // results and must match oracle/mesh_oracle.c bit for bit; fused multiply-adds are spelled fmaf().
+#include <cstdlib>
 #include <utility>
 
 #include "common.h"
@@ -21,6 +22,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
 
+#ifndef VANERF_WAVES_PER_SIMD
+#define VANERF_WAVES_PER_SIMD 2
+#endif
 constexpr int WAVES_PER_BLOCK = 4;
 constexpr int BLOCK = 64 * WAVES_PER_BLOCK;
 
@@ -44,7 +48,7 @@ constexpr int N_PHASES = 12;
 struct QueryParams {
     VanerfFrame f;
     const float* w;
-    LayerOffsets offs;
+    unsigned wbytes;
     const float* pts;
     const float* qsdf;
     const uint8_t* qvis;
@@ -55,6 +59,7 @@ struct QueryParams {
     float* out;
     uint8_t* valid;
     unsigned long long* stamps; // [waves][N_PHASES] (diagnostic build), else unused
+    unsigned* queue;            // work-queue head: next unclaimed 32-sample group (zero before the launch)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -64,18 +69,31 @@ template <int NB> struct WFrag { float v[NB]; };
 
 // Address = wave-uniform base (SGPR pair) + per-lane element offset (one VGPR): `global_load ... v_off, s[base] offset:imm`.
 // A per-lane 64-bit pointer would cost two VGPRs per 4 KB window of the unrolled stream.
-template <int NB> __device__ __forceinline__ WFrag<NB> wload(const float* p);
-template <> __device__ __forceinline__ WFrag<1> wload<1>(const float* p) { return {{p[0]}}; }
-template <> __device__ __forceinline__ WFrag<2> wload<2>(const float* p)
+// A fragments are fetched with buffer loads: `buffer_load_dword{,x2,x3,x4} v, v_off, s[rsrc:rsrc+3], s_off offen`.  The 128-bit
+// resource descriptor and the per-step byte offset `so` (a compile-time constant -> one s_mov) are scalar, the lane's byte
+// offset `vb` (lane * NB * 4) is the only VGPR of address for the whole 640 KB stream: no VALU address arithmetic at all
+// (64-bit global addressing cost two v_add_co per 4 KB window here; VALU cycles add to fp32-MFMA cycles on gfx950).
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x3 __attribute__((ext_vector_type(3)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+using WRsrc = __amdgpu_buffer_rsrc_t;
+
+template <int NB> __device__ __forceinline__ WFrag<NB> wload(WRsrc rs, unsigned so, unsigned vb)
 {
-    float2 t = *reinterpret_cast<const float2*>(p);
-    return {{t.x, t.y}};
-}
-template <> __device__ __forceinline__ WFrag<3> wload<3>(const float* p) { return {{p[0], p[1], p[2]}}; }
-template <> __device__ __forceinline__ WFrag<4> wload<4>(const float* p)
-{
-    float4 t = *reinterpret_cast<const float4*>(p);
-    return {{t.x, t.y, t.z, t.w}};
+    WFrag<NB> r;
+    if constexpr (NB == 1) {
+        r.v[0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, vb, so, 0));
+    } else if constexpr (NB == 2) {
+        const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rs, vb, so, 0);
+        r.v[0] = __uint_as_float(t.x); r.v[1] = __uint_as_float(t.y);
+    } else if constexpr (NB == 3) {
+        const u32x3 t = __builtin_amdgcn_raw_buffer_load_b96(rs, vb, so, 0);
+        r.v[0] = __uint_as_float(t.x); r.v[1] = __uint_as_float(t.y); r.v[2] = __uint_as_float(t.z);
+    } else {
+        const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs, vb, so, 0);
+        r.v[0] = __uint_as_float(t.x); r.v[1] = __uint_as_float(t.y); r.v[2] = __uint_as_float(t.z); r.v[3] = __uint_as_float(t.w);
+    }
+    return r;
 }
 
 template <class F, int... I> __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>)
@@ -99,23 +117,33 @@ template <int NB> __device__ __forceinline__ void mfma_step(f32x16 (&acc)[NB], c
 #endif
 }
 
-// Runs the T k-steps of one layer, fully unrolled.  operand(integral_constant<int, t>) returns the B operand (this
-// lane's activation) of step t; step t's A fragment lives in ring slot t % D and is re-loaded with step t + D as soon
-// as it has been consumed.  `sbase` is the wave-uniform address of step 0, `voff` = lane * NB.
-template <int NB, int T, class Op>
-__device__ __forceinline__ void run_layer(f32x16 (&acc)[NB], const float* sbase, unsigned voff, Op&& operand)
+// The register ring of one layer's A fragments.  ring_start() issues the first D loads; it is called well before the layer
+// runs (ahead of the previous layer's activation epilogue) so that the L2 latency of the ring fill is hidden.
+template <int NB> struct Ring { WFrag<NB> f[RingDepth<NB>::value]; };
+
+template <int NB, int T> __device__ __forceinline__ Ring<NB> ring_start(WRsrc rs, unsigned sbase, unsigned voff)
 {
     constexpr int D = RingDepth<NB>::value;
-    WFrag<NB> ring[D];
+    Ring<NB> r;
     static_for<D>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
-        if constexpr (i < T) ring[i] = wload<NB>(sbase + i * 64 * NB + voff);
+        if constexpr (i < T) r.f[i] = wload<NB>(rs, (sbase + i * 64 * NB) * 4u, voff);
     });
+    return r;
+}
+
+// Runs the T k-steps of one layer, fully unrolled.  operand(integral_constant<int, t>) returns the B operand (this
+// lane's activation) of step t; step t's A fragment lives in ring slot t % D and is re-loaded with step t + D as soon
+// as it has been consumed.  `sbase` is the float offset of step 0 in the stream, `voff` = lane * NB * 4 (bytes).
+template <int NB, int T, class Op>
+__device__ __forceinline__ void run_layer(f32x16 (&acc)[NB], Ring<NB>& ring, WRsrc rs, unsigned sbase, unsigned voff, Op&& operand)
+{
+    constexpr int D = RingDepth<NB>::value;
     static_for<T>([&](auto tc) {
         constexpr int t = decltype(tc)::value;
         const float b = operand(tc);
-        const WFrag<NB> a = ring[t % D];
-        if constexpr (t + D < T) ring[t % D] = wload<NB>(sbase + (t + D) * 64 * NB + voff);
+        const WFrag<NB> a = ring.f[t % D];
+        if constexpr (t + D < T) ring.f[t % D] = wload<NB>(rs, (sbase + (t + D) * 64 * NB) * 4u, voff);
         mfma_step<NB>(acc, a, b);
     });
 }
@@ -131,17 +159,20 @@ template <int NB> __device__ __forceinline__ void zero(f32x16 (&acc)[NB])
 // ---------------------------------------------------------------------------------------------
 // elementwise helpers
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// 1 / (1 + exp(-x)) on v_exp_f32 / v_rcp_f32 (1 ulp each; the gates and boundary weights they feed are compared at 1e-4)
+__device__ __forceinline__ float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.44269504f)); }
+
+// max(x, 0) as ONE v_med3_f32: fmaxf() costs two instructions (the backend first canonicalises the MFMA result)
+__device__ __forceinline__ float relu_f(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, 3.0e38f); }
 
 // torch.nn.Softplus(beta=100, threshold=20) (src/utils.py:656): x if 100x > 20 else log1p(exp(100x))/100, evaluated as
-// max(x,0) + ln2/100 * log2(1 + exp2(-|100x| * log2(e))) on the raw v_exp_f32 / v_log_f32 (1 + e is in [1,2]: no denormal
-// or range handling needed).  |error| < 1e-8 against fp64 over x in [-0.5, 0.5] (tools/probe_trig.hip).
+// max(x,0) + ln2/100 * log2(1 + exp2(-|x| * 100 log2(e))) on the raw v_exp_f32 / v_log_f32 (1 + e is in [1,2]: no denormal or
+// range handling).  Above the threshold the correction is < 2.1e-11 and x + it rounds to x (x > 0.2), so no select is
+// needed.  |error| < 1e-8 against fp64 over x in [-0.5, 0.5] (tools/probe_trig.hip).  6 VALU instructions, 2 transcendental.
 __device__ __forceinline__ float softplus100(float x)
 {
-    const float t = x * 100.0f;
-    const float e = __builtin_amdgcn_exp2f(-fabsf(t) * 1.44269504f);
-    const float r = fmaxf(x, 0.0f) + __builtin_amdgcn_logf(1.0f + e) * 6.93147181e-3f;
-    return t > 20.0f ? x : r;
+    const float e = __builtin_amdgcn_exp2f(fabsf(x) * -144.269504f);
+    return fmaf(__builtin_amdgcn_logf(1.0f + e), 6.93147181e-3f, relu_f(x));
 }
 
 template <int NB> __device__ __forceinline__ void relu(f32x16 (&a)[NB])
@@ -149,7 +180,7 @@ template <int NB> __device__ __forceinline__ void relu(f32x16 (&a)[NB])
 #pragma unroll
     for (int ob = 0; ob < NB; ++ob)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) a[ob][r] = fmaxf(a[ob][r], 0.0f);
+        for (int r = 0; r < 16; ++r) a[ob][r] = relu_f(a[ob][r]);
 }
 
 template <int NB> __device__ __forceinline__ void softplus(f32x16 (&a)[NB])
@@ -190,16 +221,23 @@ __device__ __forceinline__ float bilin_mix(const Bilin& b, float v00, float v01,
     return ((v00 * b.w00 + v01 * b.w01) + v10 * b.w10) + v11 * b.w11;
 }
 
-// C4 = number of float4 groups to gather from a channel-last map with `C` channels, starting at channel coff
-template <int C4> __device__ __forceinline__ void gather(const float* map, const Bilin& b, int C, int coff, float (&dst)[C4 * 4])
+// Load through a wave-uniform base pointer plus a 32-bit BYTE offset: the form `global_load v, v_off, s[base]` needs the
+// zero-extended 32-bit offset to be in bytes already (an element offset would have to be widened before the shift: two 64-bit
+// VALU adds per load).
+template <class T> __device__ __forceinline__ T ld_off(const void* __restrict__ base, unsigned byte_off)
 {
-    const float4* p00 = reinterpret_cast<const float4*>(map + (size_t)b.o00 * C + coff);
-    const float4* p01 = reinterpret_cast<const float4*>(map + (size_t)b.o01 * C + coff);
-    const float4* p10 = reinterpret_cast<const float4*>(map + (size_t)b.o10 * C + coff);
-    const float4* p11 = reinterpret_cast<const float4*>(map + (size_t)b.o11 * C + coff);
+    return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+
+// C4 = number of float4 groups to gather from a channel-last map with `C` channels, starting at channel coff.
+template <int C4> __device__ __forceinline__ void gather(const float* __restrict__ map, const Bilin& b, int C, int coff, float (&dst)[C4 * 4])
+{
+    const unsigned o00 = (unsigned)(b.o00 * C + coff) * 4u, o01 = (unsigned)(b.o01 * C + coff) * 4u, o10 = (unsigned)(b.o10 * C + coff) * 4u,
+                   o11 = (unsigned)(b.o11 * C + coff) * 4u;
 #pragma unroll
     for (int i = 0; i < C4; ++i) {
-        float4 a = p00[i], c = p01[i], d = p10[i], e = p11[i];
+        const float4 a = ld_off<float4>(map, o00 + 16 * i), c = ld_off<float4>(map, o01 + 16 * i), d = ld_off<float4>(map, o10 + 16 * i),
+                     e = ld_off<float4>(map, o11 + 16 * i);
         dst[4 * i + 0] = bilin_mix(b, a.x, c.x, d.x, e.x);
         dst[4 * i + 1] = bilin_mix(b, a.y, c.y, d.y, e.y);
         dst[4 * i + 2] = bilin_mix(b, a.z, c.z, d.z, e.z);
@@ -207,12 +245,11 @@ template <int C4> __device__ __forceinline__ void gather(const float* map, const
     }
 }
 
-template <int C4> __device__ __forceinline__ void load_row(const float* row, float (&dst)[C4 * 4])
+template <int C4> __device__ __forceinline__ void load_row(const float* __restrict__ table, unsigned elem_off, float (&dst)[C4 * 4])
 {
-    const float4* p = reinterpret_cast<const float4*>(row);
 #pragma unroll
     for (int i = 0; i < C4; ++i) {
-        float4 a = p[i];
+        const float4 a = ld_off<float4>(table, elem_off * 4u + 16 * i);
         dst[4 * i] = a.x; dst[4 * i + 1] = a.y; dst[4 * i + 2] = a.z; dst[4 * i + 3] = a.w;
     }
 }
@@ -220,12 +257,13 @@ template <int C4> __device__ __forceinline__ void load_row(const float* row, flo
 // one GeoVisFusion scale (src/networks.py:83-94 / 96-104): gates, gated 2-layer MLP.
 //   HC = channels per lane half (32 for the 64-channel map, 4 for the 8-channel map), NBO = output blocks,
 //   NREG_MID = registers of the last hidden block that carry real channels
-template <int HC, int NBO, int NREG_MID>
-__device__ __forceinline__ void geo_scale(const float* W, const LayerOffsets& offs, int l_at_a, int lane,
+template <int HC, int NBO, int NREG_MID, int l_at_a>
+__device__ __forceinline__ void geo_scale(WRsrc W, int lane, Ring<1>& ring_at,
                                           float (&pix)[HC], float (&nn)[HC], float (&tw)[HC], float s0, float s1,
                                           f32x16 (&outacc)[NBO])
 {
     constexpr int TIN = 3 * HC + 2;
+    constexpr int TOUT = (NBO - 1) * 16 + NREG_MID;
     auto input = [&](auto tc) -> float {
         constexpr int t = decltype(tc)::value;
         if constexpr (t < HC) return pix[t];
@@ -234,13 +272,16 @@ __device__ __forceinline__ void geo_scale(const float* W, const LayerOffsets& of
         else if constexpr (t == 3 * HC) return s0;
         else return s1;
     };
+    const unsigned v1 = (unsigned)lane * 4u, vo = (unsigned)lane * NBO * 4u; // byte offsets
     f32x16 at[1];
     zero<1>(at);
-    run_layer<1, TIN>(at, W + offs.off[l_at_a], (unsigned)lane, input);
+    run_layer<1, TIN>(at, ring_at, W, layer_offset(l_at_a), v1, input);
+    Ring<1> r_gate = ring_start<1, 6>(W, layer_offset(l_at_a + 1), v1);
+    Ring<NBO> r_mid = ring_start<NBO, TIN>(W, layer_offset(l_at_a + 2), vo);
     relu<1>(at);
     f32x16 gate[1];
     zero<1>(gate);
-    run_layer<1, 6>(gate, W + offs.off[l_at_a + 1], (unsigned)lane, [&](auto tc) -> float { return at[0][decltype(tc)::value]; });
+    run_layer<1, 6>(gate, r_gate, W, layer_offset(l_at_a + 1), v1, [&](auto tc) -> float { return at[0][decltype(tc)::value]; });
     // gates live in rows 0..2 = registers 0..2 of the h = 0 lanes
     const float a0 = __shfl(sigmoid_f(gate[0][0]), lane & 31);
     const float a1 = __shfl(sigmoid_f(gate[0][1]), lane & 31);
@@ -249,14 +290,15 @@ __device__ __forceinline__ void geo_scale(const float* W, const LayerOffsets& of
     for (int t = 0; t < HC; ++t) { pix[t] *= a0; nn[t] *= a1; tw[t] *= a2; }
     f32x16 mid[NBO];
     zero<NBO>(mid);
-    run_layer<NBO, TIN>(mid, W + offs.off[l_at_a + 2], (unsigned)lane * NBO, input);
+    run_layer<NBO, TIN>(mid, r_mid, W, layer_offset(l_at_a + 2), vo, input);
+    Ring<NBO> r_out = ring_start<NBO, TOUT>(W, layer_offset(l_at_a + 3), vo);
     relu<NBO>(mid);
     zero<NBO>(outacc);
-    run_layer<NBO, (NBO - 1) * 16 + NREG_MID>(outacc, W + offs.off[l_at_a + 3], (unsigned)lane * NBO,
-                                              [&](auto tc) -> float { constexpr int t = decltype(tc)::value; return mid[t / 16][t % 16]; });
+    run_layer<NBO, TOUT>(outacc, r_out, W, layer_offset(l_at_a + 3), vo,
+                         [&](auto tc) -> float { constexpr int t = decltype(tc)::value; return mid[t / 16][t % 16]; });
 }
 
-__global__ __launch_bounds__(BLOCK, 2) void query_kernel(const QueryParams P)
+__global__ __launch_bounds__(BLOCK, VANERF_WAVES_PER_SIMD) void query_kernel(const QueryParams P)
 {
     __shared__ float4 s_kpt[VANERF_NKPT];
     for (int i = threadIdx.x; i < VANERF_NKPT; i += BLOCK) s_kpt[i] = reinterpret_cast<const float4*>(P.f.kpt_cam)[i];
@@ -264,24 +306,30 @@ __global__ __launch_bounds__(BLOCK, 2) void query_kernel(const QueryParams P)
 
     const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
     const long long wave = (long long)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
-    const long long nwaves = (long long)gridDim.x * WAVES_PER_BLOCK;
     const long long ngroups = (P.n + 31) / 32;
     const VanerfFrame& F = P.f;
+    const WRsrc W = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.w), 0, P.wbytes, 0x00020000); // kernarg-derived: wave-uniform
     const float one_h0 = h ? 0.0f : 1.0f; // B operand of the bias k-step
 
 #ifdef VANERF_STAMPS
     unsigned long long phase_cycles[N_PHASES] = {};
-    unsigned long long t_prev;
+    unsigned long long t_prev, rt0;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt0)::"memory");
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_prev)::"memory");
 #endif
-    for (long long g = wave; g < ngroups; g += nwaves) {
-        // Opaque per-iteration zero added to the (uniform, global-address-space) weight base: keeps LICM from hoisting the
-        // ~160 4-KB-window base addresses of the unrolled fragment stream out of the loop (they would all be live at
-        // once).  The offset, not the pointer, is laundered: laundering the pointer would drop its address space and turn
-        // every fragment load into a flat_load (out-of-order return => vmcnt(0) at every use).
-        unsigned opaque_zero = 0;
-        asm volatile("" : "+s"(opaque_zero));
-        const float* __restrict__ W = P.w + opaque_zero;
+    // Dynamic work distribution: the two waves that share a SIMD do not progress at the same rate (the older one wins the
+    // issue arbitration), so a static split leaves half of the SIMDs idle for the last ~15 % of the launch.  Each wave
+    // claims one 32-sample group at a time from a device-scope counter; the next claim is issued a whole group ahead, so
+    // its latency is never exposed.  Every wave leaves the loop once the counter passes ngroups: the grid always drains.
+    auto claim = [&]() -> unsigned {
+        unsigned v = 0;
+        if (lane == 0) v = atomicAdd(P.queue, 1u);
+        return (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+    };
+    unsigned g_next = claim();
+    while (g_next < (unsigned)ngroups) {
+        const long long g = g_next;
+        g_next = claim();
         const long long s_raw = g * 32 + j;
         const bool live = s_raw < P.n;
         const long long s = live ? s_raw : P.n - 1;
@@ -299,14 +347,15 @@ __global__ __launch_bounds__(BLOCK, 2) void query_kernel(const QueryParams P)
         const float eps = 1e-2f;
         bool in_img = (x >= -1.0f - eps) && (x <= 1.0f + eps) && (y >= -1.0f - eps) && (y <= 1.0f + eps) && (zn >= -1.0f);
         const Bilin bi = bilin_setup(x, y, F.hi, F.wi);
-        float fg = bilin_mix(bi, F.mask[bi.o00], F.mask[bi.o01], F.mask[bi.o10], F.mask[bi.o11]);
+        float fg = bilin_mix(bi, ld_off<float>(F.mask, 4u * bi.o00), ld_off<float>(F.mask, 4u * bi.o01), ld_off<float>(F.mask, 4u * bi.o10),
+                              ld_off<float>(F.mask, 4u * bi.o11));
         const float mask = (in_img && fg > 0.1f) ? 1.0f : 0.0f;
         float pw;
         {
             float ux = 0.5f * x + 0.5f, uy = 0.5f * y + 0.5f, uz = 0.5f * zn + 0.5f;
             float dx = fminf(ux, 1.0f - ux), dy = fminf(uy, 1.0f - uy), dz = fminf(uz, 1.0f - uz);
-            float wx = sigmoid_f(5.0f * (dx / 0.1f - 1.0f)), wy = sigmoid_f(5.0f * (dy / 0.1f - 1.0f)),
-                  wz = sigmoid_f(5.0f * (dz / 0.1f - 1.0f));
+            float wx = sigmoid_f(5.0f * (dx * 10.0f - 1.0f)), wy = sigmoid_f(5.0f * (dy * 10.0f - 1.0f)),
+                  wz = sigmoid_f(5.0f * (dz * 10.0f - 1.0f));
             float p = (wx * wy) * wz * mask;
             pw = p / (p + 1e-6f);
         }
@@ -315,30 +364,40 @@ __global__ __launch_bounds__(BLOCK, 2) void query_kernel(const QueryParams P)
         // ---- 1-NN vertex (src/networks.py:27-33): found by vanerf_mesh_query_accel (same pass as the SDF) ----------
         const int nn_idx = P.knn_in[s];
         const int tw_idx = nn_idx >= VANERF_NV_HAND ? nn_idx - VANERF_NV_HAND : nn_idx + VANERF_NV_HAND;
-        const float vis_nn = F.vert_vis[nn_idx], vis_tw = F.vert_vis[tw_idx];
+        const float vis_nn = ld_off<float>(F.vert_vis, 4u * nn_idx), vis_tw = ld_off<float>(F.vert_vis, 4u * tw_idx);
         const float sc0 = h ? q_vis : q_sdf;   // k-pair (sdf | qvis)
         const float sc1 = h ? vis_tw : vis_nn; // k-pair (vis_nn | vis_twin)
 
         STAMP(1); // 1-NN
         // ---- GeoVisFusion (src/networks.py:75-106) ---------------------------------------------------------
+        // Every layer's fragment ring is started ahead of the previous layer's epilogue (see ring_start); the gathers of the
+        // second scale and of the texture branch are issued here too, so their L2 latency hides behind the first layers.
+        const unsigned v1 = (unsigned)lane * 4u, v2 = (unsigned)lane * 8u, v3 = (unsigned)lane * 12u, v4 = (unsigned)lane * 16u; // byte offsets
+        Ring<1> r_at0 = ring_start<1, 98>(W, layer_offset(L_GEO_AT0_A), v1);
         f32x16 g64[2], g8[1];
+        float pix8[4], nn8[4], tw8[4];
         {
             float pix[32], nn[32], tw[32];
             const Bilin b0 = bilin_setup(x, y, F.h0, F.w0);
             gather<8>(F.geo0, b0, 64, 32 * h, pix);
-            load_row<8>(F.vfeat0 + (size_t)nn_idx * 64 + 32 * h, nn);
-            load_row<8>(F.vfeat0 + (size_t)tw_idx * 64 + 32 * h, tw);
-            STAMP(2); // geo0 gathers
-            geo_scale<32, 2, 16>(W, P.offs, L_GEO_AT0_A, lane, pix, nn, tw, sc0, sc1, g64);
+            load_row<8>(F.vfeat0, (unsigned)(nn_idx * 64 + 32 * h), nn);
+            load_row<8>(F.vfeat0, (unsigned)(tw_idx * 64 + 32 * h), tw);
+            const Bilin b1 = bilin_setup(x, y, F.h1, F.w1);
+            gather<1>(F.geo1, b1, 8, 4 * h, pix8);
+            load_row<1>(F.vfeat1, (unsigned)(nn_idx * 8 + 4 * h), nn8);
+            load_row<1>(F.vfeat1, (unsigned)(tw_idx * 8 + 4 * h), tw8);
+            STAMP(2); // geo gathers
+            geo_scale<32, 2, 16, L_GEO_AT0_A>(W, lane, r_at0, pix, nn, tw, sc0, sc1, g64);
             STAMP(3); // geo0 layers
         }
+        // mlp0's ring (7 x dwordx4) starts before the small second scale runs
+        constexpr unsigned base0 = layer_offset(L_MLP0);
+        constexpr int D0 = PE_FEATS;
+        WFrag<4> ring0[D0];
         {
-            float pix[4], nn[4], tw[4];
-            const Bilin b1 = bilin_setup(x, y, F.h1, F.w1);
-            gather<1>(F.geo1, b1, 8, 4 * h, pix);
-            load_row<1>(F.vfeat1 + (size_t)nn_idx * 8 + 4 * h, nn);
-            load_row<1>(F.vfeat1 + (size_t)tw_idx * 8 + 4 * h, tw);
-            geo_scale<4, 1, 4>(W, P.offs, L_GEO_AT1_A, lane, pix, nn, tw, sc0, sc1, g8);
+            Ring<1> r_at1 = ring_start<1, 14>(W, layer_offset(L_GEO_AT1_A), v1);
+            static_for<D0>([&](auto fc) { constexpr int f = decltype(fc)::value; ring0[f] = wload<4>(W, (base0 + f * 256) * 4u, v4); });
+            geo_scale<4, 1, 4, L_GEO_AT1_A>(W, lane, r_at1, pix8, nn8, tw8, sc0, sc1, g8);
             STAMP(4); // geo1
         }
 
@@ -348,7 +407,6 @@ __global__ __launch_bounds__(BLOCK, 2) void query_kernel(const QueryParams P)
             if constexpr (t < decltype(nsteps)::value) return src[t / 16][t % 16];
             else return one_h0;
         };
-        const unsigned v1 = (unsigned)lane, v2 = (unsigned)lane * 2, v3 = (unsigned)lane * 3, v4 = (unsigned)lane * 4;
 
         // ---- mlp_geo.layers1 (src/utils.py:822-852): [PE294 | geo64] -> 128 -> 128 -> [. | geo8] -> 120 -> 64 ----
         f32x16 xv[2];
@@ -358,21 +416,19 @@ __global__ __launch_bounds__(BLOCK, 2) void query_kernel(const QueryParams P)
             {
                 // SpatialEncoder 'rel_z_decay' (src/spatial.py:71-72, 109-117) in source-camera coordinates; the 7
                 // features of key point i (one per lane half) are k-steps 7i..7i+6, their fragments ring slots 0..6
-                const float* base = W + P.offs.off[L_MLP0];
-                constexpr int D0 = PE_FEATS;
-                WFrag<4> ring[D0];
-                static_for<D0>([&](auto fc) { constexpr int f = decltype(fc)::value; ring[f] = wload<4>(base + f * 256 + v4); });
                 float cx = fmaf(pz, F.extrin[2], fmaf(py, F.extrin[1], px * F.extrin[0])) + F.extrin[3];
                 float cy = fmaf(pz, F.extrin[6], fmaf(py, F.extrin[5], px * F.extrin[4])) + F.extrin[7];
                 float cz = fmaf(pz, F.extrin[10], fmaf(py, F.extrin[9], px * F.extrin[8])) + F.extrin[11];
                 const float4* kp = s_kpt + h * PE_KPT_PER_HALF;
-                const float* nextp = base + D0 * 256;
-                for (int i = 0; i < PE_KPT_PER_HALF; ++i) {
-                    float4 k = kp[i];
-                    float ddx = cx - k.x, ddy = cy - k.y, ddz = cz - k.z;
-                    float d2 = (ddx * ddx + ddy * ddy) + ddz * ddz;
-                    float wk = __expf(-d2 * F.pe_inv_2sigma2);
-                    float dz = F.pe_scale * ddz;
+                // fully unrolled: as a run-time loop hipcc hoists the seven prefetch loads of an iteration above its first use and
+                // waits vmcnt(0) (no prefetch left), and copies the 64 accumulator registers around the back edge
+                static_for<PE_KPT_PER_HALF>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value;
+                    const float4 k = kp[i];
+                    const float ddx = cx - k.x, ddy = cy - k.y, ddz = cz - k.z;
+                    const float d2 = (ddx * ddx + ddy * ddy) + ddz * ddz;
+                    const float wk = __expf(-d2 * F.pe_inv_2sigma2);
+                    const float dz = F.pe_scale * ddz;
                     float feat[PE_FEATS];
                     // sin/cos(pi 2^l dz): v_sin_f32 / v_cos_f32 take revolutions, so the arguments are dz/2, dz, 2dz exactly
                     // (|error| < 1.6e-7 absolute over the hand's extent, tools/probe_trig.hip)
@@ -383,41 +439,55 @@ __global__ __launch_bounds__(BLOCK, 2) void query_kernel(const QueryParams P)
                     feat[5] = s2 * wk; feat[6] = c2 * wk;
                     static_for<D0>([&](auto fc) {
                         constexpr int f = decltype(fc)::value;
-                        const WFrag<4> a = ring[f];
-                        ring[f] = wload<4>(nextp + f * 256 + v4); // step 7(i+1)+f; after the last key point: the chain part below
+                        const WFrag<4> a = ring0[f];
+                        // step 7(i+1)+f; after the last key point these are the first steps of the chain part below
+                        ring0[f] = wload<4>(W, (base0 + ((i + 1) * D0 + f) * 256) * 4u, v4);
                         mfma_step<4>(a0, a, feat[f]);
                     });
-                    nextp += D0 * 256;
-                }
+                });
+                constexpr unsigned nextp = base0 + (PE_KPT_PER_HALF + 1) * D0 * 256;
                 // remaining 32 + 1 steps: geo64 (two blocks) and the bias; ring slot = step % 7 (147 = 21 * 7)
                 constexpr int TREM = 33;
                 static_for<TREM>([&](auto tc) {
                     constexpr int t = decltype(tc)::value;
                     const float b = chain(g64, tc, std::integral_constant<int, 32>{});
-                    const WFrag<4> a = ring[t % D0];
-                    if constexpr (t + D0 < TREM) ring[t % D0] = wload<4>(nextp + t * 256 + v4);
+                    const WFrag<4> a = ring0[t % D0];
+                    if constexpr (t + D0 < TREM) ring0[t % D0] = wload<4>(W, (nextp + t * 256) * 4u, v4);
                     mfma_step<4>(a0, a, b);
                 });
             }
             STAMP(5); // mlp0 (PE + geo64)
+            Ring<4> r1 = ring_start<4, 65>(W, layer_offset(L_MLP1), v4);
             softplus<4>(a0);
             f32x16 a1[4];
             zero<4>(a1);
-            run_layer<4, 65>(a1, W + P.offs.off[L_MLP1], v4, [&](auto tc) -> float { return chain(a0, tc, std::integral_constant<int, 64>{}); });
+            run_layer<4, 65>(a1, r1, W, layer_offset(L_MLP1), v4, [&](auto tc) -> float { return chain(a0, tc, std::integral_constant<int, 64>{}); });
+            Ring<4> r2 = ring_start<4, 69>(W, layer_offset(L_MLP2), v4);
             softplus<4>(a1);
             zero<4>(a0);
-            run_layer<4, 69>(a0, W + P.offs.off[L_MLP2], v4, [&](auto tc) -> float {
+            run_layer<4, 69>(a0, r2, W, layer_offset(L_MLP2), v4, [&](auto tc) -> float {
                 constexpr int t = decltype(tc)::value;
                 if constexpr (t < 64) return a1[t / 16][t % 16];
                 else if constexpr (t < 68) return g8[0][t - 64];
                 else return one_h0;
             });
+            Ring<2> r3 = ring_start<2, 61>(W, layer_offset(L_MLP3), v2);
             softplus<4>(a0);
             zero<2>(xv);
-            run_layer<2, 61>(xv, W + P.offs.off[L_MLP3], v2, [&](auto tc) -> float { return chain(a0, tc, std::integral_constant<int, 60>{}); });
+            run_layer<2, 61>(xv, r3, W, layer_offset(L_MLP3), v2, [&](auto tc) -> float { return chain(a0, tc, std::integral_constant<int, 60>{}); });
         }
         STAMP(6); // softplus x3 + mlp1..3
+        // texture-branch gathers are issued now: their latency hides behind the head and ibr layers
+        float row[32]; // h = 0: nearest vertex [img3|tex8|gf18], h = 1: twin vertex
+        float qi[4], qt[8];
+        load_row<8>(F.vfeat_tex, (unsigned)((h ? tw_idx : nn_idx) * 32), row);
+        gather<1>(F.img, bi, 4, 0, qi);
+        {
+            const Bilin bt = bilin_setup(x, y, F.ht, F.wt);
+            gather<2>(F.tex, bt, 8, 0, qt);
+        }
         // ---- PoolModule mean/var over V = 1 views (src/utils.py:744-779, 854-880) --------------------------
+        Ring<2> rh0 = ring_start<2, 65>(W, layer_offset(L_HEAD0), v2);
         f32x16 pool[4]; // [mean64 | var64]
 #pragma unroll
         for (int b = 0; b < 2; ++b)
@@ -430,32 +500,31 @@ __global__ __launch_bounds__(BLOCK, 2) void query_kernel(const QueryParams P)
             }
         // ---- mlp_geo.layers2: 128 -> 64 -> 64 -> 2 (src/utils.py:709-719) ----------------------------------
         f32x16 head[1];
+        Ring<1> r_ibr;
         {
             f32x16 m0[2], m1[2];
             zero<2>(m0);
-            run_layer<2, 65>(m0, W + P.offs.off[L_HEAD0], v2, [&](auto tc) -> float { return chain(pool, tc, std::integral_constant<int, 64>{}); });
+            run_layer<2, 65>(m0, rh0, W, layer_offset(L_HEAD0), v2, [&](auto tc) -> float { return chain(pool, tc, std::integral_constant<int, 64>{}); });
+            Ring<2> rh1 = ring_start<2, 33>(W, layer_offset(L_HEAD1), v2);
             softplus<2>(m0);
             zero<2>(m1);
-            run_layer<2, 33>(m1, W + P.offs.off[L_HEAD1], v2, [&](auto tc) -> float { return chain(m0, tc, std::integral_constant<int, 32>{}); });
+            run_layer<2, 33>(m1, rh1, W, layer_offset(L_HEAD1), v2, [&](auto tc) -> float { return chain(m0, tc, std::integral_constant<int, 32>{}); });
+            Ring<1> rh2 = ring_start<1, 33>(W, layer_offset(L_HEAD2), v1);
+            r_ibr = ring_start<1, 65>(W, layer_offset(L_IBR), v1);
             softplus<2>(m1);
             zero<1>(head);
-            run_layer<1, 33>(head, W + P.offs.off[L_HEAD2], v1, [&](auto tc) -> float { return chain(m1, tc, std::integral_constant<int, 32>{}); });
+            run_layer<1, 33>(head, rh2, W, layer_offset(L_HEAD2), v1, [&](auto tc) -> float { return chain(m1, tc, std::integral_constant<int, 32>{}); });
         }
         STAMP(7); // pool + head
         // ---- ibr_compress_gfeat 128 -> 24 (src/model.py:921) ------------------------------------------------
+        Ring<3> r_ta = ring_start<3, 49>(W, layer_offset(L_TEX_AT_A), v3);
         f32x16 lat[1];
         zero<1>(lat);
-        run_layer<1, 65>(lat, W + P.offs.off[L_IBR], v1, [&](auto tc) -> float { return chain(pool, tc, std::integral_constant<int, 64>{}); });
+        run_layer<1, 65>(lat, r_ibr, W, layer_offset(L_IBR), v1, [&](auto tc) -> float { return chain(pool, tc, std::integral_constant<int, 64>{}); });
         STAMP(8); // ibr
         // ---- TexVisFusion per-sample part (src/networks.py:281-293) -----------------------------------------
         f32x16 rgb[1];
         {
-            float row[32]; // h = 0: nearest vertex [img3|tex8|gf18], h = 1: twin vertex
-            load_row<8>(F.vfeat_tex + (size_t)(h ? tw_idx : nn_idx) * 32, row);
-            float qi[4], qt[8];
-            gather<1>(F.img, bi, 4, 0, qi);
-            const Bilin bt = bilin_setup(x, y, F.ht, F.wt);
-            gather<2>(F.tex, bt, 8, 0, qt);
             float q[6];
             q[0] = h ? qt[3] : qi[0]; q[1] = h ? qt[4] : qi[1]; q[2] = h ? qt[5] : qi[2];
             q[3] = h ? qt[6] : qt[0]; q[4] = h ? qt[7] : qt[1]; q[5] = h ? 0.0f : qt[2];
@@ -470,13 +539,16 @@ __global__ __launch_bounds__(BLOCK, 2) void query_kernel(const QueryParams P)
                 else if constexpr (t == 47) return t0;
                 else return t1;
             };
+            auto from_ta = [&](auto& ta_) { return [&](auto tc) -> float { constexpr int t = decltype(tc)::value; return ta_[t / 16][t % 16]; }; };
             f32x16 ta[3];
             zero<3>(ta);
-            run_layer<3, 49>(ta, W + P.offs.off[L_TEX_AT_A], v3, tex_in);
+            run_layer<3, 49>(ta, r_ta, W, layer_offset(L_TEX_AT_A), v3, tex_in);
+            Ring<1> r_tg = ring_start<1, 48>(W, layer_offset(L_TEX_AT_B), v1);
             relu<3>(ta);
             f32x16 tg[1];
             zero<1>(tg);
-            run_layer<1, 48>(tg, W + P.offs.off[L_TEX_AT_B], v1, [&](auto tc) -> float { constexpr int t = decltype(tc)::value; return ta[t / 16][t % 16]; });
+            run_layer<1, 48>(tg, r_tg, W, layer_offset(L_TEX_AT_B), v1, from_ta(ta));
+            Ring<3> r_tb = ring_start<3, 49>(W, layer_offset(L_TEX_A), v3);
             // six gates: rows 0..3 -> h = 0 lanes regs 0..3, rows 4,5 -> h = 1 lanes regs 0,1
             float m0 = sigmoid_f(tg[0][0]), m1 = sigmoid_f(tg[0][1]), m2 = sigmoid_f(tg[0][2]), m3 = sigmoid_f(tg[0][3]);
             float o0 = __shfl_xor(m0, 32), o1 = __shfl_xor(m1, 32), o2 = __shfl_xor(m2, 32);
@@ -493,10 +565,11 @@ __global__ __launch_bounds__(BLOCK, 2) void query_kernel(const QueryParams P)
 #pragma unroll
             for (int r = 0; r < 12; ++r) latg[r] = lat[0][r] * glat;
             zero<3>(ta);
-            run_layer<3, 49>(ta, W + P.offs.off[L_TEX_A], v3, tex_in);
+            run_layer<3, 49>(ta, r_tb, W, layer_offset(L_TEX_A), v3, tex_in);
+            Ring<1> r_rgb = ring_start<1, 48>(W, layer_offset(L_TEX_B), v1);
             relu<3>(ta);
             zero<1>(rgb);
-            run_layer<1, 48>(rgb, W + P.offs.off[L_TEX_B], v1, [&](auto tc) -> float { constexpr int t = decltype(tc)::value; return ta[t / 16][t % 16]; });
+            run_layer<1, 48>(rgb, r_rgb, W, layer_offset(L_TEX_B), v1, from_ta(ta));
         }
         STAMP(9); // tex
         // ---- eval_func (src/model.py:1140-1160): rows 0,1 of the head / 0..2 of the colour live in the h = 0 lanes ----
@@ -514,6 +587,9 @@ __global__ __launch_bounds__(BLOCK, 2) void query_kernel(const QueryParams P)
         STAMP(10); // store
     }
 #ifdef VANERF_STAMPS
+    unsigned long long rt1;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt1)::"memory");
+    phase_cycles[N_PHASES - 1] = rt1 - rt0; // 100 MHz reference clock over the same span: clock = sum(phases) / this * 100 MHz
     if (P.stamps && lane == 0)
         for (int k = 0; k < N_PHASES; ++k) P.stamps[wave * N_PHASES + k] = phase_cycles[k];
 #endif
@@ -529,21 +605,30 @@ extern "C" int vanerf_query_samples(const VanerfWeights* w, const VanerfFrame* f
         if (!w || !w->dev || !frame || !pts || !query_sdf || !query_vis || !knn_idx || !out) throw_error("vanerf_query_samples: null argument");
         if (n < 0) throw_error("vanerf_query_samples: n = %lld < 0", (long long)n);
         if (n == 0) return;
+        if ((n + 31) / 32 >= 0xffffff00LL) throw_error("vanerf_query_samples: n = %lld too large for one launch", (long long)n);
         const VanerfFrame& f = *frame;
         if (!f.geo0 || !f.geo1 || !f.tex || !f.img || !f.mask || !f.verts || !f.vfeat0 || !f.vfeat1 || !f.vfeat_tex || !f.vert_vis || !f.kpt_cam)
             throw_error("vanerf_query_samples: frame has a null pointer");
         if (f.h0 < 1 || f.w0 < 1 || f.h1 < 1 || f.w1 < 1 || f.ht < 1 || f.wt < 1 || f.hi < 1 || f.wi < 1)
             throw_error("vanerf_query_samples: feature-map sizes must be positive");
         QueryParams P;
-        P.f = f; P.w = w->dev; P.offs = w->offs; P.pts = pts; P.qsdf = query_sdf; P.qvis = query_vis; P.noise = noise; P.knn_in = knn_idx; P.raw = raw;
+        P.f = f; P.w = w->dev; P.wbytes = (unsigned)(w->n_floats * sizeof(float)); P.pts = pts; P.qsdf = query_sdf; P.qvis = query_vis; P.noise = noise; P.knn_in = knn_idx; P.raw = raw;
         P.n = n; P.out = out; P.valid = valid; P.stamps = nullptr;
         long long ngroups = (n + 31) / 32;
         long long blocks = (ngroups + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
         int dev = 0, cus = 256;
         HIP_CHECK(hipGetDevice(&dev));
         HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-        long long cap = (long long)cus * 2; // two 256-thread blocks per CU (launch bounds), persistent waves stride over groups
+        // Two 4-wave blocks per CU = two waves per SIMD (256 VGPRs each).  fp32 MFMA and fp32 VALU do not overlap on gfx950
+        // (tools/probe_mfma_valu.hip: every VALU instruction adds its issue cycles to the MFMA time), so the second wave does not
+        // hide VALU work behind MFMAs; what it hides is load latency and the in-order issue gaps of its partner.
+        int per_cu = 2;
+        if (const char* e = getenv("VANERF_BLOCKS_PER_CU")) per_cu = atoi(e) > 0 ? atoi(e) : 2; // experiment knob
+        long long cap = (long long)cus * per_cu;
         if (blocks > cap) blocks = cap;
+        VanerfWeights* wm = const_cast<VanerfWeights*>(w);
+        P.queue = wm->queues + (wm->next_queue++ % VanerfWeights::N_QUEUES);
+        HIP_CHECK(hipMemsetAsync(P.queue, 0, sizeof(unsigned), (hipStream_t)stream));
         hipLaunchKernelGGL(query_kernel, dim3((unsigned)blocks), dim3(BLOCK), 0, (hipStream_t)stream, P);
         HIP_CHECK(hipGetLastError());
     });
@@ -556,12 +641,17 @@ extern "C" int vanerf_debug_query_stamps(const VanerfWeights* w, const VanerfFra
 {
     return guarded([&] {
         QueryParams P;
-        P.f = *frame; P.w = w->dev; P.offs = w->offs; P.pts = pts; P.qsdf = query_sdf; P.qvis = query_vis; P.noise = nullptr; P.knn_in = knn_idx; P.raw = 0;
+        P.f = *frame; P.w = w->dev; P.wbytes = (unsigned)(w->n_floats * sizeof(float)); P.pts = pts; P.qsdf = query_sdf; P.qvis = query_vis; P.noise = nullptr; P.knn_in = knn_idx; P.raw = 0;
         P.n = n; P.out = out; P.valid = nullptr; P.stamps = stamps;
         long long ngroups = (n + 31) / 32;
         long long blocks = (ngroups + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
-        if (blocks > 512) blocks = 512;
+        long long capd = 512;
+        if (const char* e = getenv("VANERF_BLOCKS_PER_CU")) capd = 256LL * (atoi(e) > 0 ? atoi(e) : 2);
+        if (blocks > capd) blocks = capd;
         *n_waves = (int)blocks * WAVES_PER_BLOCK;
+        VanerfWeights* wm = const_cast<VanerfWeights*>(w);
+        P.queue = wm->queues + (wm->next_queue++ % VanerfWeights::N_QUEUES);
+        HIP_CHECK(hipMemsetAsync(P.queue, 0, sizeof(unsigned), (hipStream_t)stream));
         if (stamps) hipLaunchKernelGGL(query_kernel, dim3((unsigned)blocks), dim3(BLOCK), 0, (hipStream_t)stream, P);
         HIP_CHECK(hipGetLastError());
     });

@@ -115,7 +115,10 @@ namespace vanerf {
 void pack_weights_host(const VanerfWeightTable& w, std::vector<float>& out, LayerOffsets& offs)
 {
     out.clear();
-    auto begin = [&](int l) { offs.off[l] = (unsigned)out.size(); };
+    auto begin = [&](int l) {
+        offs.off[l] = (unsigned)out.size();
+        if (offs.off[l] != layer_offset(l)) throw_error("internal: layer %d starts at %u, layer_spec.h says %u", l, offs.off[l], layer_offset(l));
+    };
 
     // ---- GeoVisFusion (src/networks.py:75-106) ------------------------------------------------
     {
