@@ -151,10 +151,13 @@ typedef struct {
     int nvc;
 } VanerfMeshAccel;
 
-/* knn_idx (may be NULL): 1-NN vertex of every point (knn_points K=1, src/networks.py:28), found in the same pass. */
+/* knn_idx (may be NULL): 1-NN vertex of every point (knn_points K=1, src/networks.py:28), found in the same pass.
+ * grid_nx, grid_ny, grid_s: optional layout hint (0,0,0 = none): pts are the samples of a grid_nx x grid_ny ray grid with grid_s
+ * samples per ray in the reference's order (sample index = ray * grid_s + depth); lets a wave work on 64 neighbouring points.
+ * The results do not depend on the hint.                                                                                      */
 int vanerf_mesh_query_accel(const VanerfMeshAccel* accel, const float* verts, int nv, const int32_t* faces, int nf,
                             const float* vert_vis, const float* pts, int64_t n, float* sdf, uint8_t* vis, int32_t* face,
-                            int32_t* knn_idx, void* stream);
+                            int32_t* knn_idx, int grid_nx, int grid_ny, int grid_s, void* stream);
 
 /* a10 knn_points K=1 (src/networks.py:28): verts[NV][4], pts[N][3] -> idx[N] int32 (first minimum). */
 int vanerf_knn1(const float* verts4, int nv, const float* pts, int64_t n, int32_t* idx, void* stream);

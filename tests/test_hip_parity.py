@@ -113,6 +113,8 @@ def test_mesh_query_accel_equals_brute_force(R):
         assert torch.equal(s0, s1) and torch.equal(v0, v1) and torch.equal(f0, f1)
         v4 = torch.cat([verts, torch.zeros(verts.shape[0], 1, device="cuda")], 1).contiguous()
         assert torch.equal(k1, R.knn1(v4, p))  # cluster-pruned 1-NN == exhaustive 1-NN (== oracle, test_knn1_bit_exact)
+        s2, v2, f2, k2 = R.mesh_query_accel(accel, verts, faces, vv, p, want_face=True, grid=(50, 75, 16))  # 50*75*16 = 60000: layout hint
+        assert torch.equal(s0, s2) and torch.equal(v0, v2) and torch.equal(f0, f2) and torch.equal(k1, k2)
         assert 0.02 < (s0 < 0).float().mean() < 0.9
 
 

@@ -245,7 +245,7 @@ __global__ __launch_bounds__(MA_BLOCK) void mesh_query_accel_kernel(const Vanerf
                                                                     const int32_t* __restrict__ F, const float* __restrict__ vert_vis,
                                                                     const float* __restrict__ P, long long n, float* __restrict__ sdf,
                                                                     uint8_t* __restrict__ vis, int32_t* __restrict__ face,
-                                                                    int32_t* __restrict__ knn)
+                                                                    int32_t* __restrict__ knn, int gnx, int gny, int gS)
 {
     // dynamic LDS: [nc][6] triangle-cluster boxes | [nvc][6] vertex-cluster boxes | [nvc*16] sorted vertices (float4)
     extern __shared__ float4 s_dyn[];
@@ -256,7 +256,27 @@ __global__ __launch_bounds__(MA_BLOCK) void mesh_query_accel_kernel(const Vanerf
     for (int k = threadIdx.x; k < A.nvc * 6; k += MA_BLOCK) s_vbox[k] = A.vbox[k];
     for (int k = threadIdx.x; k < A.nvc * CL; k += MA_BLOCK) s_vs[k] = reinterpret_cast<const float4*>(A.vsort)[k];
     __syncthreads();
-    for (long long i = (long long)blockIdx.x * MA_BLOCK + threadIdx.x; i < n; i += (long long)gridDim.x * MA_BLOCK) {
+    // Work mapping.  The pruning below is data dependent, so a wave runs the UNION of its lanes' candidate lists.  With the
+    // ray-grid hint (gnx x gny rays, gS samples per ray, sample index = ray * gS + depth) a wave takes one depth of an 8 x 8
+    // pixel tile: 64 points a few millimetres apart that prune almost identically.  Without the hint (gnx == 0) consecutive
+    // lanes take consecutive samples (one whole ray per wave: its points span the bounding box, ~4x more work per wave).
+    const int lane = threadIdx.x & 63;
+    const long long wave0 = ((long long)blockIdx.x * MA_BLOCK + threadIdx.x) >> 6, nwaves = ((long long)gridDim.x * MA_BLOCK) >> 6;
+    const int ntx = (gnx + 7) >> 3, nty = (gny + 7) >> 3;
+    const long long nwork = gnx > 0 ? (long long)ntx * nty * gS : (n + 63) >> 6;
+    for (long long w = wave0; w < nwork; w += nwaves) {
+        long long i;
+        if (gnx > 0) {
+            const int d = (int)(w % gS);
+            const long long tile = w / gS;
+            const int tx = (int)(tile % ntx), ty = (int)(tile / ntx);
+            const int rx = tx * 8 + (lane & 7), ry = ty * 8 + (lane >> 3);
+            if (rx >= gnx || ry >= gny) continue;
+            i = ((long long)ry * gnx + rx) * gS + d;
+        } else {
+            i = w * 64 + lane;
+            if (i >= n) continue;
+        }
         const f3 p = {P[3 * i], P[3 * i + 1], P[3 * i + 2]};
         // ---- 1-NN vertex (knn_points K=1, src/networks.py:28): clusters of 16 Morton-sorted vertices; squared distance
         //      ((dx*dx + dy*dy) + dz*dz), first minimum in ORIGINAL vertex order (oracle/mesh_oracle.c:knn1)
@@ -399,7 +419,7 @@ extern "C" int vanerf_knn1(const float* verts4, int nv, const float* pts, int64_
 
 extern "C" int vanerf_mesh_query_accel(const VanerfMeshAccel* accel, const float* verts, int nv, const int32_t* faces, int nf,
                                        const float* vert_vis, const float* pts, int64_t n, float* sdf, uint8_t* vis, int32_t* face,
-                                       int32_t* knn_idx, void* stream)
+                                       int32_t* knn_idx, int grid_nx, int grid_ny, int grid_s, void* stream)
 {
     return guarded([&] {
         if (!accel || !verts || !faces || !vert_vis || !pts || !sdf || !vis) throw_error("vanerf_mesh_query_accel: null argument");
@@ -413,10 +433,12 @@ extern "C" int vanerf_mesh_query_accel(const VanerfMeshAccel* accel, const float
         const size_t lds = sizeof(float) * ((size_t)A.nvc * CL * 4 + (size_t)A.nvc * 6 + (size_t)A.nc * 6);
         if (lds > 64 * 1024) throw_error("vanerf_mesh_query_accel: mesh too large for the LDS-resident tables (%zu bytes)", lds);
         if (n == 0) return;
+        if (grid_nx != 0 && (grid_nx < 0 || grid_ny <= 0 || grid_s <= 0 || (long long)grid_nx * grid_ny * grid_s != n))
+            throw_error("vanerf_mesh_query_accel: ray-grid hint %d x %d x %d does not match n = %lld", grid_nx, grid_ny, grid_s, (long long)n);
         long long blocks = (n + MA_BLOCK - 1) / MA_BLOCK;
         if (blocks > 256 * 8) blocks = 256 * 8;
         hipLaunchKernelGGL(mesh_query_accel_kernel, dim3((unsigned)blocks), dim3(MA_BLOCK), lds, (hipStream_t)stream, A, verts, faces, vert_vis,
-                           pts, (long long)n, sdf, vis, face, knn_idx);
+                           pts, (long long)n, sdf, vis, face, knn_idx, grid_nx, grid_ny, grid_s);
         HIP_CHECK(hipGetLastError());
     });
 }

@@ -317,8 +317,10 @@ def mesh_query(verts3, faces_i32, vert_vis, pts, want_face=False):
     return (sdf, vis, face) if want_face else (sdf, vis)
 
 
-def mesh_query_accel(accel, verts3, faces_i32, vert_vis, pts, want_face=False, want_knn=True):
-    """Same results as mesh_query (+ knn1), through the per-frame acceleration structure: sdf, vis[, face][, knn]."""
+def mesh_query_accel(accel, verts3, faces_i32, vert_vis, pts, want_face=False, want_knn=True, grid=None):
+    """Same results as mesh_query (+ knn1), through the per-frame acceleration structure: sdf, vis[, face][, knn].
+    grid = (nx, ny, S): pts are the samples of an nx x ny ray grid, S per ray, ray-major (speed hint only)."""
+    gnx, gny, gs = grid if grid is not None else (0, 0, 0)
     n = pts.shape[0]
     sdf = torch.empty(n, dtype=torch.float32, device=pts.device)
     vis = torch.empty(n, dtype=torch.uint8, device=pts.device)
@@ -326,7 +328,7 @@ def mesh_query_accel(accel, verts3, faces_i32, vert_vis, pts, want_face=False, w
     knn = torch.empty(n, dtype=torch.int32, device=pts.device) if want_knn else None
     check(lib.vanerf_mesh_query_accel(byref(accel.c), _ptr(verts3, torch.float32), verts3.shape[0], _ptr(faces_i32, torch.int32),
                                       faces_i32.shape[0], _ptr(vert_vis, torch.float32), _ptr(pts, torch.float32), n, _ptr(sdf), _ptr(vis),
-                                      _ptr(face), _ptr(knn), _stream()))
+                                      _ptr(face), _ptr(knn), int(gnx), int(gny), int(gs), _stream()))
     return tuple(t for t in (sdf, vis, face, knn) if t is not None)
 
 
@@ -467,7 +469,8 @@ def render_pass(weights, frame, cam_tar, bounds, x0, y0, step, nx, ny, sample_pe
 
     def evaluate(z):
         pts = sample_points(rays["rays_d"], rays["cam_pos"], z)
-        q_sdf, q_vis, knn = mesh_query_accel(frame.accel, frame.verts3, frame.faces, frame.vert_vis, pts)
+        grid = (nx, ny, z.shape[1]) if pixels is None else None
+        q_sdf, q_vis, knn = mesh_query_accel(frame.accel, frame.verts3, frame.faces, frame.vert_vis, pts, grid=grid)
         noise = None
         if noise_std > 0.0:  # th.randn_like(rad) * rand_noise_std (src/model.py:1155-1156), drawn on the device
             noise = torch.randn(pts.shape[0], device=pts.device, generator=generator) * noise_std
