@@ -136,6 +136,12 @@ def main():
     k_samples = [n for _, _, n in events]
     kern_s = sum(k_ms) / 1e3
     achieved = sum(k_samples) * FLOP_PER_SAMPLE / kern_s / 1e12
+    traffic = None  # HBM bytes per launch from the committed PMC passes (bytes per sample x samples per launch)
+    try:
+        pm = json.load(open(os.path.join(REPO, "profiles", "r01_query_kernel_traffic.json")))
+        traffic = (pm["fetch_kb"] + pm["write_kb"]) * 1024.0 / pm["samples"] * (sum(k_samples) / len(events))
+    except (OSError, KeyError, ValueError):
+        pass
     rays_total = H * W
     result = {
         "metric": "rendered rays/sec (64 samples/ray) + PSNR vs ref, 512x334 view", "value": rays_total * args.steps / dt, "unit": "rays/s",
@@ -147,7 +153,7 @@ def main():
                                                    "note": "fine composite re-uses the coarse evaluations (bit-identical, tests/test_hip_parity.py)"},
                    "rays": rays_total, "parallelism": f"rays{world}" if world > 1 else "single"},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
-                     "traffic": None, "kernel": "query_kernel (v_mfma_f32_32x32x2_f32)", "launches": len(events),
+                     "traffic": traffic, "traffic_unit": "HBM bytes per launch (FETCH_SIZE + WRITE_SIZE, profiles/r01_query_kernel_traffic.json)", "kernel": "query_kernel (v_mfma_f32_32x32x2_f32)", "launches": len(events),
                      "avg_launch_ms": statistics.mean(k_ms), "kernel_ms_per_step": sum(k_ms) / args.steps,
                      "flop_per_launch_avg": sum(k_samples) * FLOP_PER_SAMPLE / len(events)},
     }
