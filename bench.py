@@ -23,6 +23,7 @@ if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
 FLOP_PER_SAMPLE = 2 * 143772          # 143 772 MAC per sample evaluation (V = 1)
+FLOP_PER_INVALID_SAMPLE = 2 * (3072 + 22848)  # ibr_compress + TexVisFusion only: all that an invalid sample needs
 PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 
 
@@ -121,6 +122,7 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
+    short0 = weights.short_groups()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         img = step(events)
@@ -131,11 +133,16 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
 
-    # dominant kernel: query_kernel, two launches per step (coarse R*S and fine R*2S samples)
+    # dominant kernel: query_kernel, two launches per step (R*S coarse samples, R*S new importance samples).
+    # Algorithmic FLOPs of a launch = 287 544 per sample, except that a 32-sample group whose samples ALL miss the source view
+    # needs only the colour branch (51 840 FLOP per sample): the kernel counts those groups and they are priced at that figure,
+    # so skipped work never inflates `achieved`.
     k_ms = [e0.elapsed_time(e1) for e0, e1, _ in events]
     k_samples = [n for _, _, n in events]
     kern_s = sum(k_ms) / 1e3
-    achieved = sum(k_samples) * FLOP_PER_SAMPLE / kern_s / 1e12
+    short_samples = 32 * (weights.short_groups() - short0)
+    flops = (sum(k_samples) - short_samples) * FLOP_PER_SAMPLE + short_samples * FLOP_PER_INVALID_SAMPLE
+    achieved = flops / kern_s / 1e12
     traffic = None  # HBM bytes per launch from the committed PMC passes (bytes per sample x samples per launch)
     try:
         pm = json.load(open(os.path.join(REPO, "profiles", "r01_query_kernel_traffic.json")))
@@ -155,7 +162,8 @@ def main():
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
                      "traffic": traffic, "traffic_unit": "HBM bytes per launch (FETCH_SIZE + WRITE_SIZE, profiles/r01_query_kernel_traffic.json)", "kernel": "query_kernel (v_mfma_f32_32x32x2_f32)", "launches": len(events),
                      "avg_launch_ms": statistics.mean(k_ms), "kernel_ms_per_step": sum(k_ms) / args.steps,
-                     "flop_per_launch_avg": sum(k_samples) * FLOP_PER_SAMPLE / len(events)},
+                     "flop_per_launch_avg": flops / len(events), "samples_per_launch_avg": sum(k_samples) / len(events),
+                     "all_invalid_group_fraction": short_samples / max(1, sum(k_samples))},
     }
     if rank == 0 and world == 1 and args.cpu_rays_side > 0:
         base, ref, grids = cpu_baseline(sd, frame, S, args.cpu_rays_side)

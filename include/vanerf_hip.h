@@ -99,6 +99,9 @@ const char* vanerf_last_error(void);
 /* Packs the weight table into MFMA fragment order on the device.  mode: 0 = fp32 (exact, v_mfma_f32_32x32x2_f32). */
 int vanerf_weights_pack(const VanerfWeightTable* w, int mode, VanerfWeights** out);
 int vanerf_weights_free(VanerfWeights* w);
+/* Diagnostics: number of 32-sample groups (since the pack) for which vanerf_query_samples took its all-invalid short path
+ * (only the colour branch evaluated).  Blocking device read; for benchmarks and tests.                                        */
+int vanerf_weights_short_groups(const VanerfWeights* w, uint64_t* count);
 /* Host-only view of the packed fragment stream (no GPU touched): out[cap] or NULL to query the size; offsets[20]. */
 int vanerf_weights_pack_host(const VanerfWeightTable* w, float* out, int64_t cap, int64_t* n_out, unsigned* offsets);
 

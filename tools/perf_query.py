@@ -35,4 +35,6 @@ for _ in range(args.iters):
     ts.append(e0.elapsed_time(e1))
 n = pts.shape[0]
 best = min(ts)
-print(f"samples {n}  ms min {best:.3f} med {sorted(ts)[len(ts)//2]:.3f}  TFLOP/s(alg) {n * 287544 / best / 1e9:.2f}  frac {n * 287544 / best / 1e9 / 157.3:.3f}  checksum {out.double().sum().item():.6f}")
+short = 32 * w.short_groups() / (args.iters + 1) / n
+flop = n * ((1 - short) * 287544 + short * 51840)
+print(f"samples {n}  ms min {best:.3f} med {sorted(ts)[len(ts)//2]:.3f}  short-path {short:.3f}  TFLOP/s(alg) {flop / best / 1e9:.2f}  frac {flop / best / 1e9 / 157.3:.3f}  checksum {out.double().sum().item():.6f}")

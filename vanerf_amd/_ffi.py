@@ -5,7 +5,7 @@ module raises.  Build it with `python -m vanerf_amd.build` (or `__graft_entry__.
 """
 import ctypes
 import os
-from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int64, c_uint, c_void_p
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int64, c_uint, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libvanerf_hip.so")
@@ -55,6 +55,7 @@ _SIGS = {
     "vanerf_last_error": (c_char_p, []),
     "vanerf_weights_pack": (c_int, [POINTER(VanerfWeightTable), c_int, POINTER(c_void_p)]),
     "vanerf_weights_free": (c_int, [c_void_p]),
+    "vanerf_weights_short_groups": (c_int, [c_void_p, POINTER(c_uint64)]),
     "vanerf_weights_pack_host": (c_int, [POINTER(VanerfWeightTable), _FP, c_int64, POINTER(c_int64), POINTER(c_uint)]),
     "vanerf_ray_setup": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, POINTER(c_float), POINTER(c_float), c_float, c_float,
                                  POINTER(c_float), c_int, _FP, _FP, _FP, _FP, _FP, _FP, _FP, _FP, _FP, c_void_p]),

@@ -36,9 +36,12 @@ extern "C" int vanerf_weights_pack(const VanerfWeightTable* w, int mode, VanerfW
         if (e == hipSuccess) e = hipMalloc(&h->dev, host.size() * sizeof(float));
         if (e == hipSuccess) e = hipMemcpy(h->dev, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMalloc(&h->queues, VanerfWeights::N_QUEUES * sizeof(unsigned));
+        if (e == hipSuccess) e = hipMalloc(&h->stats, sizeof(unsigned long long));
+        if (e == hipSuccess) e = hipMemset(h->stats, 0, sizeof(unsigned long long));
         if (e != hipSuccess) {
             if (h->dev) (void)hipFree(h->dev);
             if (h->queues) (void)hipFree(h->queues);
+            if (h->stats) (void)hipFree(h->stats);
             delete h;
             hip_check(e, "vanerf_weights_pack: device upload");
         }
@@ -52,6 +55,7 @@ extern "C" int vanerf_weights_free(VanerfWeights* w)
         if (!w) return;
         if (w->dev) HIP_CHECK(hipFree(w->dev));
         if (w->queues) HIP_CHECK(hipFree(w->queues));
+        if (w->stats) HIP_CHECK(hipFree(w->stats));
         delete w;
     });
 }
@@ -70,5 +74,17 @@ extern "C" int vanerf_weights_pack_host(const VanerfWeightTable* w, float* out, 
             if (cap < (int64_t)host.size()) throw_error("vanerf_weights_pack_host: buffer too small");
             std::copy(host.begin(), host.end(), out);
         }
+    });
+}
+
+// Running count (since the handle was packed) of 32-sample groups for which vanerf_query_samples skipped GeoVisFusion / mlp_geo
+// because every sample of the group was invalid.  Synchronises the device; meant for benchmarks and tests, not for the render loop.
+extern "C" int vanerf_weights_short_groups(const VanerfWeights* w, uint64_t* count)
+{
+    return guarded([&] {
+        if (!w || !count) throw_error("vanerf_weights_short_groups: null argument");
+        unsigned long long v = 0;
+        HIP_CHECK(hipMemcpy(&v, w->stats, sizeof v, hipMemcpyDeviceToHost));
+        *count = v;
     });
 }

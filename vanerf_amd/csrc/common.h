@@ -77,4 +77,5 @@ struct VanerfWeights {
     static constexpr int N_QUEUES = 64;
     unsigned* queues = nullptr;
     unsigned next_queue = 0;
+    unsigned long long* stats = nullptr; // [0]: running count of 32-sample groups that took query_kernel's all-invalid short path
 };

@@ -60,6 +60,7 @@ struct QueryParams {
     uint8_t* valid;
     unsigned long long* stamps; // [waves][N_PHASES] (diagnostic build), else unused
     unsigned* queue;            // work-queue head: next unclaimed 32-sample group (zero before the launch)
+    unsigned long long* short_groups; // optional: += number of groups that took the all-invalid short path
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -326,6 +327,7 @@ __global__ __launch_bounds__(BLOCK, VANERF_WAVES_PER_SIMD) void query_kernel(con
         if (lane == 0) v = atomicAdd(P.queue, 1u);
         return (unsigned)__builtin_amdgcn_readfirstlane((int)v);
     };
+    unsigned short_groups = 0;
     unsigned g_next = claim();
     while (g_next < (unsigned)ngroups) {
         const long long g = g_next;
@@ -373,148 +375,159 @@ __global__ __launch_bounds__(BLOCK, VANERF_WAVES_PER_SIMD) void query_kernel(con
         // Every layer's fragment ring is started ahead of the previous layer's epilogue (see ring_start); the gathers of the
         // second scale and of the texture branch are issued here too, so their L2 latency hides behind the first layers.
         const unsigned v1 = (unsigned)lane * 4u, v2 = (unsigned)lane * 8u, v3 = (unsigned)lane * 12u, v4 = (unsigned)lane * 16u; // byte offsets
-        Ring<1> r_at0 = ring_start<1, 98>(W, layer_offset(L_GEO_AT0_A), v1);
-        f32x16 g64[2], g8[1];
-        float pix8[4], nn8[4], tw8[4];
-        {
-            float pix[32], nn[32], tw[32];
-            const Bilin b0 = bilin_setup(x, y, F.h0, F.w0);
-            gather<8>(F.geo0, b0, 64, 32 * h, pix);
-            load_row<8>(F.vfeat0, (unsigned)(nn_idx * 64 + 32 * h), nn);
-            load_row<8>(F.vfeat0, (unsigned)(tw_idx * 64 + 32 * h), tw);
-            const Bilin b1 = bilin_setup(x, y, F.h1, F.w1);
-            gather<1>(F.geo1, b1, 8, 4 * h, pix8);
-            load_row<1>(F.vfeat1, (unsigned)(nn_idx * 8 + 4 * h), nn8);
-            load_row<1>(F.vfeat1, (unsigned)(tw_idx * 8 + 4 * h), tw8);
-            STAMP(2); // geo gathers
-            geo_scale<32, 2, 16, L_GEO_AT0_A>(W, lane, r_at0, pix, nn, tw, sc0, sc1, g64);
-            STAMP(3); // geo0 layers
-        }
-        // mlp0's ring (7 x dwordx4) starts before the small second scale runs
-        constexpr unsigned base0 = layer_offset(L_MLP0);
-        constexpr int D0 = PE_FEATS;
-        WFrag<4> ring0[D0];
-        {
-            Ring<1> r_at1 = ring_start<1, 14>(W, layer_offset(L_GEO_AT1_A), v1);
-            static_for<D0>([&](auto fc) { constexpr int f = decltype(fc)::value; ring0[f] = wload<4>(W, (base0 + f * 256) * 4u, v4); });
-            geo_scale<4, 1, 4, L_GEO_AT1_A>(W, lane, r_at1, pix8, nn8, tw8, sc0, sc1, g8);
-            STAMP(4); // geo1
-        }
-
         // chain operand: register r of block b of a previous accumulator array, then the bias step
         auto chain = [&](auto& src, auto tc, auto nsteps) -> float {
             constexpr int t = decltype(tc)::value;
             if constexpr (t < decltype(nsteps)::value) return src[t / 16][t % 16];
             else return one_h0;
         };
-
-        // ---- mlp_geo.layers1 (src/utils.py:822-852): [PE294 | geo64] -> 128 -> 128 -> [. | geo8] -> 120 -> 64 ----
-        f32x16 xv[2];
-        {
-            f32x16 a0[4];
-            zero<4>(a0);
-            {
-                // SpatialEncoder 'rel_z_decay' (src/spatial.py:71-72, 109-117) in source-camera coordinates; the 7
-                // features of key point i (one per lane half) are k-steps 7i..7i+6, their fragments ring slots 0..6
-                float cx = fmaf(pz, F.extrin[2], fmaf(py, F.extrin[1], px * F.extrin[0])) + F.extrin[3];
-                float cy = fmaf(pz, F.extrin[6], fmaf(py, F.extrin[5], px * F.extrin[4])) + F.extrin[7];
-                float cz = fmaf(pz, F.extrin[10], fmaf(py, F.extrin[9], px * F.extrin[8])) + F.extrin[11];
-                const float4* kp = s_kpt + h * PE_KPT_PER_HALF;
-                // fully unrolled: as a run-time loop hipcc hoists the seven prefetch loads of an iteration above its first use and
-                // waits vmcnt(0) (no prefetch left), and copies the 64 accumulator registers around the back edge
-                static_for<PE_KPT_PER_HALF>([&](auto ic) {
-                    constexpr int i = decltype(ic)::value;
-                    const float4 k = kp[i];
-                    const float ddx = cx - k.x, ddy = cy - k.y, ddz = cz - k.z;
-                    const float d2 = (ddx * ddx + ddy * ddy) + ddz * ddz;
-                    const float wk = __expf(-d2 * F.pe_inv_2sigma2);
-                    const float dz = F.pe_scale * ddz;
-                    float feat[PE_FEATS];
-                    // sin/cos(pi 2^l dz): v_sin_f32 / v_cos_f32 take revolutions, so the arguments are dz/2, dz, 2dz exactly
-                    // (|error| < 1.6e-7 absolute over the hand's extent, tools/probe_trig.hip)
-                    const float s0 = __builtin_amdgcn_sinf(0.5f * dz), c0 = __builtin_amdgcn_cosf(0.5f * dz);
-                    const float s1 = __builtin_amdgcn_sinf(dz), c1 = __builtin_amdgcn_cosf(dz);
-                    const float s2 = __builtin_amdgcn_sinf(2.0f * dz), c2 = __builtin_amdgcn_cosf(2.0f * dz);
-                    feat[0] = dz * wk; feat[1] = s0 * wk; feat[2] = c0 * wk; feat[3] = s1 * wk; feat[4] = c1 * wk;
-                    feat[5] = s2 * wk; feat[6] = c2 * wk;
-                    static_for<D0>([&](auto fc) {
-                        constexpr int f = decltype(fc)::value;
-                        const WFrag<4> a = ring0[f];
-                        // step 7(i+1)+f; after the last key point these are the first steps of the chain part below
-                        ring0[f] = wload<4>(W, (base0 + ((i + 1) * D0 + f) * 256) * 4u, v4);
-                        mfma_step<4>(a0, a, feat[f]);
-                    });
-                });
-                constexpr unsigned nextp = base0 + (PE_KPT_PER_HALF + 1) * D0 * 256;
-                // remaining 32 + 1 steps: geo64 (two blocks) and the bias; ring slot = step % 7 (147 = 21 * 7)
-                constexpr int TREM = 33;
-                static_for<TREM>([&](auto tc) {
-                    constexpr int t = decltype(tc)::value;
-                    const float b = chain(g64, tc, std::integral_constant<int, 32>{});
-                    const WFrag<4> a = ring0[t % D0];
-                    if constexpr (t + D0 < TREM) ring0[t % D0] = wload<4>(W, (nextp + t * 256) * 4u, v4);
-                    mfma_step<4>(a0, a, b);
-                });
-            }
-            STAMP(5); // mlp0 (PE + geo64)
-            Ring<4> r1 = ring_start<4, 65>(W, layer_offset(L_MLP1), v4);
-            softplus<4>(a0);
-            f32x16 a1[4];
-            zero<4>(a1);
-            run_layer<4, 65>(a1, r1, W, layer_offset(L_MLP1), v4, [&](auto tc) -> float { return chain(a0, tc, std::integral_constant<int, 64>{}); });
-            Ring<4> r2 = ring_start<4, 69>(W, layer_offset(L_MLP2), v4);
-            softplus<4>(a1);
-            zero<4>(a0);
-            run_layer<4, 69>(a0, r2, W, layer_offset(L_MLP2), v4, [&](auto tc) -> float {
-                constexpr int t = decltype(tc)::value;
-                if constexpr (t < 64) return a1[t / 16][t % 16];
-                else if constexpr (t < 68) return g8[0][t - 64];
-                else return one_h0;
-            });
-            Ring<2> r3 = ring_start<2, 61>(W, layer_offset(L_MLP3), v2);
-            softplus<4>(a0);
-            zero<2>(xv);
-            run_layer<2, 61>(xv, r3, W, layer_offset(L_MLP3), v2, [&](auto tc) -> float { return chain(a0, tc, std::integral_constant<int, 60>{}); });
-        }
-        STAMP(6); // softplus x3 + mlp1..3
-        // texture-branch gathers are issued now: their latency hides behind the head and ibr layers
         float row[32]; // h = 0: nearest vertex [img3|tex8|gf18], h = 1: twin vertex
         float qi[4], qt[8];
-        load_row<8>(F.vfeat_tex, (unsigned)((h ? tw_idx : nn_idx) * 32), row);
-        gather<1>(F.img, bi, 4, 0, qi);
-        {
+        auto tex_gathers = [&]() { // issued ~2 layers before the texture branch needs them
+            load_row<8>(F.vfeat_tex, (unsigned)((h ? tw_idx : nn_idx) * 32), row);
+            gather<1>(F.img, bi, 4, 0, qi);
             const Bilin bt = bilin_setup(x, y, F.ht, F.wt);
             gather<2>(F.tex, bt, 8, 0, qt);
-        }
-        // ---- PoolModule mean/var over V = 1 views (src/utils.py:744-779, 854-880) --------------------------
-        Ring<2> rh0 = ring_start<2, 65>(W, layer_offset(L_HEAD0), v2);
+        };
         f32x16 pool[4]; // [mean64 | var64]
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float m = pw * xv[b][r];
-                float d = xv[b][r] - m;
-                pool[b][r] = m;
-                pool[2 + b][r] = pw * (d * d);
-            }
-        // ---- mlp_geo.layers2: 128 -> 64 -> 64 -> 2 (src/utils.py:709-719) ----------------------------------
         f32x16 head[1];
-        Ring<1> r_ibr;
-        {
-            f32x16 m0[2], m1[2];
-            zero<2>(m0);
-            run_layer<2, 65>(m0, rh0, W, layer_offset(L_HEAD0), v2, [&](auto tc) -> float { return chain(pool, tc, std::integral_constant<int, 64>{}); });
-            Ring<2> rh1 = ring_start<2, 33>(W, layer_offset(L_HEAD1), v2);
-            softplus<2>(m0);
-            zero<2>(m1);
-            run_layer<2, 33>(m1, rh1, W, layer_offset(L_HEAD1), v2, [&](auto tc) -> float { return chain(m0, tc, std::integral_constant<int, 32>{}); });
-            Ring<1> rh2 = ring_start<1, 33>(W, layer_offset(L_HEAD2), v1);
-            r_ibr = ring_start<1, 65>(W, layer_offset(L_IBR), v1);
-            softplus<2>(m1);
+        // A sample whose projection misses the source view / foreground mask has pixel weight 0: its pooled latent is exactly
+        // zero (0 * x), the density head is masked out by eval_func and only the colour branch (fed by the bias of
+        // ibr_compress) survives.  When ALL 32 samples of the wave are such samples, GeoVisFusion, mlp_geo.layers1 and the head
+        // (82 % of the MFMAs) are skipped -- same bits, wave-uniform branch.  With real foreground masks most samples are.
+        const bool any_valid = __builtin_amdgcn_ballot_w64(mask > 0.0f) != 0ull;
+        if (any_valid) {
+            Ring<1> r_at0 = ring_start<1, 98>(W, layer_offset(L_GEO_AT0_A), v1);
+            f32x16 g64[2], g8[1];
+            float pix8[4], nn8[4], tw8[4];
+            {
+                float pix[32], nn[32], tw[32];
+                const Bilin b0 = bilin_setup(x, y, F.h0, F.w0);
+                gather<8>(F.geo0, b0, 64, 32 * h, pix);
+                load_row<8>(F.vfeat0, (unsigned)(nn_idx * 64 + 32 * h), nn);
+                load_row<8>(F.vfeat0, (unsigned)(tw_idx * 64 + 32 * h), tw);
+                const Bilin b1 = bilin_setup(x, y, F.h1, F.w1);
+                gather<1>(F.geo1, b1, 8, 4 * h, pix8);
+                load_row<1>(F.vfeat1, (unsigned)(nn_idx * 8 + 4 * h), nn8);
+                load_row<1>(F.vfeat1, (unsigned)(tw_idx * 8 + 4 * h), tw8);
+                STAMP(2); // geo gathers
+                geo_scale<32, 2, 16, L_GEO_AT0_A>(W, lane, r_at0, pix, nn, tw, sc0, sc1, g64);
+                STAMP(3); // geo0 layers
+            }
+            // mlp0's ring (7 x dwordx4) starts before the small second scale runs
+            constexpr unsigned base0 = layer_offset(L_MLP0);
+            constexpr int D0 = PE_FEATS;
+            WFrag<4> ring0[D0];
+            {
+                Ring<1> r_at1 = ring_start<1, 14>(W, layer_offset(L_GEO_AT1_A), v1);
+                static_for<D0>([&](auto fc) { constexpr int f = decltype(fc)::value; ring0[f] = wload<4>(W, (base0 + f * 256) * 4u, v4); });
+                geo_scale<4, 1, 4, L_GEO_AT1_A>(W, lane, r_at1, pix8, nn8, tw8, sc0, sc1, g8);
+                STAMP(4); // geo1
+            }
+
+
+            // ---- mlp_geo.layers1 (src/utils.py:822-852): [PE294 | geo64] -> 128 -> 128 -> [. | geo8] -> 120 -> 64 ----
+            f32x16 xv[2];
+            {
+                f32x16 a0[4];
+                zero<4>(a0);
+                {
+                    // SpatialEncoder 'rel_z_decay' (src/spatial.py:71-72, 109-117) in source-camera coordinates; the 7
+                    // features of key point i (one per lane half) are k-steps 7i..7i+6, their fragments ring slots 0..6
+                    float cx = fmaf(pz, F.extrin[2], fmaf(py, F.extrin[1], px * F.extrin[0])) + F.extrin[3];
+                    float cy = fmaf(pz, F.extrin[6], fmaf(py, F.extrin[5], px * F.extrin[4])) + F.extrin[7];
+                    float cz = fmaf(pz, F.extrin[10], fmaf(py, F.extrin[9], px * F.extrin[8])) + F.extrin[11];
+                    const float4* kp = s_kpt + h * PE_KPT_PER_HALF;
+                    // fully unrolled: as a run-time loop hipcc hoists the seven prefetch loads of an iteration above its first use and
+                    // waits vmcnt(0) (no prefetch left), and copies the 64 accumulator registers around the back edge
+                    static_for<PE_KPT_PER_HALF>([&](auto ic) {
+                        constexpr int i = decltype(ic)::value;
+                        const float4 k = kp[i];
+                        const float ddx = cx - k.x, ddy = cy - k.y, ddz = cz - k.z;
+                        const float d2 = (ddx * ddx + ddy * ddy) + ddz * ddz;
+                        const float wk = __expf(-d2 * F.pe_inv_2sigma2);
+                        const float dz = F.pe_scale * ddz;
+                        float feat[PE_FEATS];
+                        // sin/cos(pi 2^l dz): v_sin_f32 / v_cos_f32 take revolutions, so the arguments are dz/2, dz, 2dz exactly
+                        // (|error| < 1.6e-7 absolute over the hand's extent, tools/probe_trig.hip)
+                        const float s0 = __builtin_amdgcn_sinf(0.5f * dz), c0 = __builtin_amdgcn_cosf(0.5f * dz);
+                        const float s1 = __builtin_amdgcn_sinf(dz), c1 = __builtin_amdgcn_cosf(dz);
+                        const float s2 = __builtin_amdgcn_sinf(2.0f * dz), c2 = __builtin_amdgcn_cosf(2.0f * dz);
+                        feat[0] = dz * wk; feat[1] = s0 * wk; feat[2] = c0 * wk; feat[3] = s1 * wk; feat[4] = c1 * wk;
+                        feat[5] = s2 * wk; feat[6] = c2 * wk;
+                        static_for<D0>([&](auto fc) {
+                            constexpr int f = decltype(fc)::value;
+                            const WFrag<4> a = ring0[f];
+                            // step 7(i+1)+f; after the last key point these are the first steps of the chain part below
+                            ring0[f] = wload<4>(W, (base0 + ((i + 1) * D0 + f) * 256) * 4u, v4);
+                            mfma_step<4>(a0, a, feat[f]);
+                        });
+                    });
+                    constexpr unsigned nextp = base0 + (PE_KPT_PER_HALF + 1) * D0 * 256;
+                    // remaining 32 + 1 steps: geo64 (two blocks) and the bias; ring slot = step % 7 (147 = 21 * 7)
+                    constexpr int TREM = 33;
+                    static_for<TREM>([&](auto tc) {
+                        constexpr int t = decltype(tc)::value;
+                        const float b = chain(g64, tc, std::integral_constant<int, 32>{});
+                        const WFrag<4> a = ring0[t % D0];
+                        if constexpr (t + D0 < TREM) ring0[t % D0] = wload<4>(W, (nextp + t * 256) * 4u, v4);
+                        mfma_step<4>(a0, a, b);
+                    });
+                }
+                STAMP(5); // mlp0 (PE + geo64)
+                Ring<4> r1 = ring_start<4, 65>(W, layer_offset(L_MLP1), v4);
+                softplus<4>(a0);
+                f32x16 a1[4];
+                zero<4>(a1);
+                run_layer<4, 65>(a1, r1, W, layer_offset(L_MLP1), v4, [&](auto tc) -> float { return chain(a0, tc, std::integral_constant<int, 64>{}); });
+                Ring<4> r2 = ring_start<4, 69>(W, layer_offset(L_MLP2), v4);
+                softplus<4>(a1);
+                zero<4>(a0);
+                run_layer<4, 69>(a0, r2, W, layer_offset(L_MLP2), v4, [&](auto tc) -> float {
+                    constexpr int t = decltype(tc)::value;
+                    if constexpr (t < 64) return a1[t / 16][t % 16];
+                    else if constexpr (t < 68) return g8[0][t - 64];
+                    else return one_h0;
+                });
+                Ring<2> r3 = ring_start<2, 61>(W, layer_offset(L_MLP3), v2);
+                softplus<4>(a0);
+                zero<2>(xv);
+                run_layer<2, 61>(xv, r3, W, layer_offset(L_MLP3), v2, [&](auto tc) -> float { return chain(a0, tc, std::integral_constant<int, 60>{}); });
+            }
+            STAMP(6); // softplus x3 + mlp1..3
+            tex_gathers();
+            // ---- PoolModule mean/var over V = 1 views (src/utils.py:744-779, 854-880) --------------------------
+            Ring<2> rh0 = ring_start<2, 65>(W, layer_offset(L_HEAD0), v2);
+    #pragma unroll
+            for (int b = 0; b < 2; ++b)
+    #pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float m = pw * xv[b][r];
+                    float d = xv[b][r] - m;
+                    pool[b][r] = m;
+                    pool[2 + b][r] = pw * (d * d);
+                }
+            // ---- mlp_geo.layers2: 128 -> 64 -> 64 -> 2 (src/utils.py:709-719) ----------------------------------
+            {
+                f32x16 m0[2], m1[2];
+                zero<2>(m0);
+                run_layer<2, 65>(m0, rh0, W, layer_offset(L_HEAD0), v2, [&](auto tc) -> float { return chain(pool, tc, std::integral_constant<int, 64>{}); });
+                Ring<2> rh1 = ring_start<2, 33>(W, layer_offset(L_HEAD1), v2);
+                softplus<2>(m0);
+                zero<2>(m1);
+                run_layer<2, 33>(m1, rh1, W, layer_offset(L_HEAD1), v2, [&](auto tc) -> float { return chain(m0, tc, std::integral_constant<int, 32>{}); });
+                Ring<1> rh2 = ring_start<1, 33>(W, layer_offset(L_HEAD2), v1);
+                softplus<2>(m1);
+                zero<1>(head);
+                run_layer<1, 33>(head, rh2, W, layer_offset(L_HEAD2), v1, [&](auto tc) -> float { return chain(m1, tc, std::integral_constant<int, 32>{}); });
+            }
+        } else {
+            tex_gathers();
+            zero<4>(pool);
             zero<1>(head);
-            run_layer<1, 33>(head, rh2, W, layer_offset(L_HEAD2), v1, [&](auto tc) -> float { return chain(m1, tc, std::integral_constant<int, 32>{}); });
+            if (lane == 0) ++short_groups;
         }
+        Ring<1> r_ibr = ring_start<1, 65>(W, layer_offset(L_IBR), v1);
         STAMP(7); // pool + head
         // ---- ibr_compress_gfeat 128 -> 24 (src/model.py:921) ------------------------------------------------
         Ring<3> r_ta = ring_start<3, 49>(W, layer_offset(L_TEX_AT_A), v3);
@@ -586,6 +599,7 @@ __global__ __launch_bounds__(BLOCK, VANERF_WAVES_PER_SIMD) void query_kernel(con
         }
         STAMP(10); // store
     }
+    if (P.short_groups && lane == 0 && short_groups) atomicAdd(P.short_groups, (unsigned long long)short_groups);
 #ifdef VANERF_STAMPS
     unsigned long long rt1;
     asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt1)::"memory");
@@ -613,7 +627,7 @@ extern "C" int vanerf_query_samples(const VanerfWeights* w, const VanerfFrame* f
             throw_error("vanerf_query_samples: feature-map sizes must be positive");
         QueryParams P;
         P.f = f; P.w = w->dev; P.wbytes = (unsigned)(w->n_floats * sizeof(float)); P.pts = pts; P.qsdf = query_sdf; P.qvis = query_vis; P.noise = noise; P.knn_in = knn_idx; P.raw = raw;
-        P.n = n; P.out = out; P.valid = valid; P.stamps = nullptr;
+        P.n = n; P.out = out; P.valid = valid; P.stamps = nullptr; P.short_groups = w->stats;
         long long ngroups = (n + 31) / 32;
         long long blocks = (ngroups + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
         int dev = 0, cus = 256;
@@ -642,7 +656,7 @@ extern "C" int vanerf_debug_query_stamps(const VanerfWeights* w, const VanerfFra
     return guarded([&] {
         QueryParams P;
         P.f = *frame; P.w = w->dev; P.wbytes = (unsigned)(w->n_floats * sizeof(float)); P.pts = pts; P.qsdf = query_sdf; P.qvis = query_vis; P.noise = nullptr; P.knn_in = knn_idx; P.raw = 0;
-        P.n = n; P.out = out; P.valid = nullptr; P.stamps = stamps;
+        P.n = n; P.out = out; P.valid = nullptr; P.stamps = stamps; P.short_groups = nullptr;
         long long ngroups = (n + 31) / 32;
         long long blocks = (ngroups + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
         long long capd = 512;

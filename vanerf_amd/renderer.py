@@ -99,6 +99,12 @@ class PackedWeights:
         self.handle = h
         self.beta = max(float(tab.sigmoid_beta), 2e-3)  # sdf_activation clamp (src/model.py:880)
 
+    def short_groups(self):
+        """Groups of 32 samples (since packing) whose query took the all-invalid short path (blocking read; diagnostics)."""
+        n = ctypes.c_uint64()
+        check(lib.vanerf_weights_short_groups(self.handle, byref(n)))
+        return int(n.value)
+
     def close(self):
         if getattr(self, "handle", None) and lib is not None:  # `lib` is None during interpreter shutdown
             lib.vanerf_weights_free(self.handle)
