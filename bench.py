@@ -76,6 +76,7 @@ def main():
     ap.add_argument("--height", type=int, default=512)
     ap.add_argument("--width", type=int, default=334)
     ap.add_argument("--samples", type=int, default=64)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo only for single-GPU rehearsals)")
     ap.add_argument("--cpu-rays-side", type=int, default=64, help="cpu_baseline sample: side of the strided ray grid (0 = skip)")
     args = ap.parse_args()
 
@@ -84,12 +85,17 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if os.environ.get("VANERF_SHARE_GPU0"):  # rehearsal of the N-rank flow on a one-GPU box (with --backend gloo)
+        local = 0
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(args.backend)
 
     from vanerf_amd import renderer, synth
     from vanerf_amd.parallel import shard_rows
@@ -109,8 +115,13 @@ def main():
                                    kernel_events=record, y_step=rows[1])
         tile = out["color_fine"]
         if world > 1:
-            full = torch.empty(world * tile.shape[0], 3, device=tile.device)
-            dist.all_gather_into_tensor(full, tile)
+            if args.backend == "nccl":
+                full = torch.empty(world * tile.shape[0], 3, device=tile.device)
+                dist.all_gather_into_tensor(full, tile)
+            else:  # gloo rehearsal: host-staged gather
+                parts = [torch.empty_like(tile, device="cpu") for _ in range(world)]
+                dist.all_gather(parts, tile.cpu())
+                full = torch.cat(parts, 0).to(tile.device)
             return full
         return tile
 
@@ -128,7 +139,7 @@ def main():
         img = step(events)
     barrier()
     dt = time.perf_counter() - t0
-    t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+    t = torch.tensor([dt], device="cuda" if args.backend == "nccl" else "cpu", dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
@@ -177,6 +188,12 @@ def main():
         result["parity"] = {"psnr_db": orc.psnr(got, want), "max_abs_err": err.max().item(),
                             "frac_pixels_above_1e-4": (err.max(1)[0] > 1e-4).float().mean().item(), "pixels": int(idx.numel())}
         result["speedup_vs_cpu"] = result["value"] / base["value"]
+    if world > 1:  # the gathered, de-interleaved image must contain this rank's own rows at their place
+        from vanerf_amd.parallel import deinterleave
+        full_img = deinterleave(img, H, W, world)
+        own = step()
+        own = own.view(world, rows[2], W, 3)[rank] if own.shape[0] == H * W else own.view(rows[2], W, 3)
+        assert torch.equal(full_img[rows[0]::rows[1]], own), "gathered image does not contain this rank's rows"
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:

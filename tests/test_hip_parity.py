@@ -407,3 +407,36 @@ def test_model_training_patch_and_noise(net):
         net.eval()
     assert out["tex_fg_fine"].shape == (1, 3, 64, 64) and torch.isfinite(out["tex_fg_fine"]).all()
     assert out["tar_alpha"].shape == (1, 1, 64, 64) if "tar_alpha" in out else True
+
+
+def test_edge_cases_and_config3(R, sd_full):
+    """Ragged / tiny / empty launches and the 128+128-sample configuration (BASELINE config 3)."""
+    frame = _frame(5, 64, 70.0, True)
+    fdat = _frame_data(R, sd_full, frame)
+    w = R.PackedWeights(sd_full)
+    # empty and single-sample launches
+    e3, e1 = torch.empty(0, 3, device="cuda"), torch.empty(0, device="cuda")
+    assert R.query_samples(w, fdat, e3, e1, torch.empty(0, dtype=torch.uint8, device="cuda"), torch.empty(0, dtype=torch.int32, device="cuda")).shape == (0, 5)
+    assert R.mesh_query_accel(fdat.accel, fdat.verts3, fdat.faces, fdat.vert_vis, e3)[0].shape == (0,)
+    p = dev(_points_near_mesh(frame, 97, seed=9))  # 97 = 3 * 32 + 1: ragged last group, every prefix must agree
+    s, v, k = R.mesh_query_accel(fdat.accel, fdat.verts3, fdat.faces, fdat.vert_vis, p)
+    full = R.query_samples(w, fdat, p, s, v, k)
+    for n in (1, 31, 32, 33, 96):
+        part = R.query_samples(w, fdat, p[:n].contiguous(), s[:n].contiguous(), v[:n].contiguous(), k[:n].contiguous())
+        assert torch.equal(part, full[:n]), n
+    # 128 + 128 samples per ray on a 5 x 7 ray grid (odd sizes), against the oracle
+    nx, ny, S = 5, 7, 128
+    out = R.render_pass(w, fdat, frame["cam_tar"], frame["bounds"], 2, 1, 9, nx, ny, S, S)
+    gy, gx = torch.meshgrid(torch.arange(ny) * 9 + 1, torch.arange(nx) * 9 + 2, indexing="ij")
+    fr = dict(frame)
+    fr["out_hw"] = (ny, nx)
+    ref = orc.batch_render(sd_full, fr, 1, None, S, S, grids=torch.stack([gx, gy], -1).view(1, -1, 2))
+    assert torch.equal(out["index"].cpu(), ref["index"][0])
+    assert out["z_fine"].shape == (nx * ny, 2 * S)
+    assert_close_frac(out["color_fine"].cpu().view(ny, nx, 3).permute(2, 0, 1), ref["tex_fg_fine"][0], TOL, 0.03, "tex_fg_fine")
+    assert_close_frac(out["depth_fine"].cpu().view(ny, nx), ref["depth_fine"][0], TOL, 0.03, "depth_fine")
+    # errors: wrong dtype / CPU tensors are refused with exceptions, not computed elsewhere
+    with pytest.raises((TypeError, ValueError)):
+        R.query_samples(w, fdat, p.double(), s, v, k)
+    with pytest.raises(ValueError):
+        R.query_samples(w, fdat, p.cpu(), s, v, k)

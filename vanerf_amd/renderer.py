@@ -149,9 +149,16 @@ def tex_global_vertex_feature(sd, feat_tex, img, pre="tex_vis_fusion."):
     gf = stack(feat_tex, "fconv3", feat_tex.shape[-1]).reshape(feat_tex.shape[0], 42, -1)
     gf_img = stack(img, "fconv4", img.shape[-1]).reshape(img.shape[0], 42, -1)
     gf = torch.cat([gf_img, gf], -1)
-    x = F.conv1d(gf, sd[pre + "fconv_gt.0.weight"], padding=1)
+    def conv1d_k3(x, w):
+        # Conv1d(k=3, padding=1) over the 18-long axis as one GEMM (rocBLAS): MIOpen falls back to a naive kernel (1.6 ms per call,
+        # 48 calls while it searches) for these 42->779->1558-channel, length-18 convolutions
+        xp = F.pad(x, (1, 1))
+        cols = torch.stack([xp[..., 0:-2], xp[..., 1:-1], xp[..., 2:]], 2).reshape(x.shape[0], -1, x.shape[-1])  # (B, C*3, L)
+        return w.reshape(w.shape[0], -1) @ cols
+
+    x = conv1d_k3(gf, sd[pre + "fconv_gt.0.weight"])
     x = torch.relu(F.layer_norm(x, [18], sd[pre + "fconv_gt.1.weight"], sd[pre + "fconv_gt.1.bias"], 1e-6))
-    x = F.conv1d(x, sd[pre + "fconv_gt.3.weight"], padding=1)
+    x = conv1d_k3(x, sd[pre + "fconv_gt.3.weight"])
     return torch.relu(F.layer_norm(x, [18], sd[pre + "fconv_gt.4.weight"], sd[pre + "fconv_gt.4.bias"], 1e-6))
 
 
