@@ -34,6 +34,7 @@ def test_error_convention(ffi):
     assert rc == -22 and b"null" in ffi.lib.vanerf_last_error()
     rc = ffi.lib.vanerf_knn1(ctypes.c_void_p(8), 0, ctypes.c_void_p(8), 1, ctypes.c_void_p(8), None)
     assert rc == -22 and b"nv=0" in ffi.lib.vanerf_last_error()
+    assert ffi.lib.vanerf_knn1(None, 4, None, 0, None, None) == 0  # an empty batch is valid
     with pytest.raises(ffi.VanerfError):
         ffi.check(rc)
 

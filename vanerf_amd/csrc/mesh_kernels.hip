@@ -396,6 +396,7 @@ extern "C" int vanerf_mesh_query(const float* verts, int nv, const int32_t* face
                                  int64_t n, float* sdf, uint8_t* vis, int32_t* face, void* stream)
 {
     return guarded([&] {
+        if (n == 0) return;
         if (!verts || !faces || !vert_vis || !pts || !sdf || !vis) throw_error("vanerf_mesh_query: null argument");
         if (nv <= 0 || nf <= 0 || n < 0) throw_error("vanerf_mesh_query: nv=%d nf=%d n=%lld", nv, nf, (long long)n);
         if (n == 0) return;
@@ -408,6 +409,7 @@ extern "C" int vanerf_mesh_query(const float* verts, int nv, const int32_t* face
 extern "C" int vanerf_knn1(const float* verts4, int nv, const float* pts, int64_t n, int32_t* idx, void* stream)
 {
     return guarded([&] {
+        if (n == 0) return;
         if (!verts4 || !pts || !idx) throw_error("vanerf_knn1: null argument");
         if (nv <= 0 || nv > 8192 || n < 0) throw_error("vanerf_knn1: nv=%d n=%lld", nv, (long long)n);
         if (n == 0) return;
@@ -422,6 +424,7 @@ extern "C" int vanerf_mesh_query_accel(const VanerfMeshAccel* accel, const float
                                        int32_t* knn_idx, int grid_nx, int grid_ny, int grid_s, void* stream)
 {
     return guarded([&] {
+        if (n == 0) return; // an empty batch is valid (and has null data pointers)
         if (!accel || !verts || !faces || !vert_vis || !pts || !sdf || !vis) throw_error("vanerf_mesh_query_accel: null argument");
         const VanerfMeshAccel& A = *accel;
         if (!A.tri || !A.sphere || !A.orig || !A.cbox || !A.cell_start || !A.cell_tri) throw_error("vanerf_mesh_query_accel: accel has a null pointer");

@@ -616,9 +616,9 @@ extern "C" int vanerf_query_samples(const VanerfWeights* w, const VanerfFrame* f
                                     uint8_t* valid, void* stream)
 {
     return guarded([&] {
-        if (!w || !w->dev || !frame || !pts || !query_sdf || !query_vis || !knn_idx || !out) throw_error("vanerf_query_samples: null argument");
         if (n < 0) throw_error("vanerf_query_samples: n = %lld < 0", (long long)n);
-        if (n == 0) return;
+        if (n == 0) return; // an empty batch is valid (and has null data pointers)
+        if (!w || !w->dev || !frame || !pts || !query_sdf || !query_vis || !knn_idx || !out) throw_error("vanerf_query_samples: null argument");
         if ((n + 31) / 32 >= 0xffffff00LL) throw_error("vanerf_query_samples: n = %lld too large for one launch", (long long)n);
         const VanerfFrame& f = *frame;
         if (!f.geo0 || !f.geo1 || !f.tex || !f.img || !f.mask || !f.verts || !f.vfeat0 || !f.vfeat1 || !f.vfeat_tex || !f.vert_vis || !f.kpt_cam)
