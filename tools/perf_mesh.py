@@ -1,0 +1,26 @@
+"""Times mesh_query_accel_kernel alone on the coarse samples of the benchmark view."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from vanerf_amd import renderer as R, synth  # noqa: E402
+
+sd = synth.make_full_weights(0)
+frame = synth.make_frame(seed=11, tar_h=512, tar_w=334, orbit_deg=15.0)
+fd = synth.to_device(frame, "cuda")
+sdd = {k: v.cuda() for k, v in sd.items() if k.startswith("tex_vis_fusion.")}
+fdat = R.FrameData(sdd, fd["img_in"], fd["feat_geo"], fd["feat_tex"], fd["src_foreground_mask"], fd["cam_in"], fd["targets"], fd["sp_data"])
+rays = R.ray_setup(frame["cam_tar"], frame["bounds"], 0, 0, 1, 334, 512, 64, device="cuda")
+pts = R.sample_points(rays["rays_d"], rays["cam_pos"], rays["z"])
+for grid in ((334, 512, 64), None):
+    ts = []
+    for _ in range(4):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = R.mesh_query_accel(fdat.accel, fdat.verts3, fdat.faces, fdat.vert_vis, pts, grid=grid)
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    print(f"grid hint {grid}: ms min {min(ts):.3f}  hit-bbox fraction {rays['hit'].float().mean().item():.3f}  inside {float((out[0] < 0).float().mean()):.4f}")
