@@ -227,6 +227,26 @@ def test_query_samples_vs_oracle(R, sd_full, seed, half):
     assert (sig_ref - sig_got).abs().max() * beta <= TOL
 
 
+def test_query_samples_split_bf16_vs_oracle(R, sd_full):
+    """mode 1 (W_hi X_hi + W_hi X_lo + W_lo X_hi on bf16 MFMA, fp32 accumulate) holds the same 1e-4 bar; plain bf16 would not (4e-3)."""
+    frame = _frame(3, 64, 8.0, True)
+    pts = _points_near_mesh(frame, 4096 + 17, seed=2)
+    verts = frame["targets"]["vert_world"]
+    xy01, z01 = orc.source_vert_xyz01(verts, frame["cam_in"])
+    q_sdf, q_vis, vert_vis, _ = orc.cal_vis_sdf_batch(verts, frame["targets"]["face_world"].long(), pts[None], xy01, z01)
+    view = torch.nn.functional.normalize(torch.ones_like(pts), dim=-1)[None]
+    rgba, valid = orc.query(sd_full, pts[None], frame["cam_in"], frame["targets"], frame["feat_geo"], frame["feat_tex"], vert_vis, q_vis, q_sdf,
+                            frame["sp_data"], frame["img_in"], view, frame["src_foreground_mask"])
+    ref = orc.eval_func(sd_full, rgba, valid, frame["cam_in"]["nml_scale"])[0]
+    fdat = _frame_data(R, sd_full, frame)
+    w1 = R.PackedWeights(sd_full, mode=1)
+    knn = R.knn1(fdat.verts4, dev(pts))
+    got = R.query_samples(w1, fdat, dev(pts), dev(q_sdf[0].contiguous()), dev(q_vis[0, :, 0].to(torch.uint8).contiguous()), knn).cpu()
+    err = (got - ref).abs()
+    print("split-bf16 query_samples max abs err [alpha, sdf, r, g, b]:", err.max(0)[0].tolist())
+    assert err.max() <= TOL
+
+
 def test_query_samples_vs_reference_golden(R, sd_full, golden):
     """Golden vector produced by the reference's own VANeRF.query (tests/golden/query.npz)."""
     g = golden("query")

@@ -15,7 +15,8 @@ frame = synth.make_frame(seed=11, tar_h=512, tar_w=334, orbit_deg=15.0)
 fd = synth.to_device(frame, "cuda")
 sdd = {k: v.cuda() for k, v in sd.items() if k.startswith("tex_vis_fusion.")}
 fdat = R.FrameData(sdd, fd["img_in"], fd["feat_geo"], fd["feat_tex"], fd["src_foreground_mask"], fd["cam_in"], fd["targets"], fd["sp_data"])
-w = R.PackedWeights(sd)
+MODE = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+w = R.PackedWeights(sd, mode=MODE)
 rays = R.ray_setup(frame["cam_tar"], frame["bounds"], 0, 0, 1, 334, 512, 64, device="cuda")
 pts = R.sample_points(rays["rays_d"], rays["cam_pos"], rays["z"])
 q_sdf, q_vis, knn = R.mesh_query_accel(fdat.accel, fdat.verts3, fdat.faces, fdat.vert_vis, pts)

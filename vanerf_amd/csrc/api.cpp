@@ -19,14 +19,14 @@ extern "C" int vanerf_weights_pack(const VanerfWeightTable* w, int mode, VanerfW
 {
     return guarded([&] {
         if (!w || !out) throw_error("vanerf_weights_pack: null argument");
-        if (mode != 0) throw_error("vanerf_weights_pack: mode %d not supported (0 = fp32 MFMA)", mode);
+        if (mode != 0 && mode != 1) throw_error("vanerf_weights_pack: mode %d not supported (0 = fp32 MFMA, 1 = split-bf16 x3)", mode);
         const float* const* ptrs = reinterpret_cast<const float* const*>(w);
         constexpr size_t n_ptrs = offsetof(VanerfWeightTable, sigmoid_beta) / sizeof(const float*);
         for (size_t i = 0; i < n_ptrs; ++i)
             if (!ptrs[i]) throw_error("vanerf_weights_pack: weight pointer #%d is null", (int)i);
         std::vector<float> host;
         LayerOffsets offs{};
-        pack_weights_host(*w, host, offs);
+        pack_weights_host(*w, host, offs, mode);
         auto* h = new VanerfWeights();
         h->n_floats = host.size();
         h->offs = offs;

@@ -62,7 +62,7 @@ int guarded(F&& fn) noexcept
     }
 }
 
-void pack_weights_host(const VanerfWeightTable& w, std::vector<float>& out, LayerOffsets& offs);
+void pack_weights_host(const VanerfWeightTable& w, std::vector<float>& out, LayerOffsets& offs, int mode = 0);
 
 } // namespace vanerf
 

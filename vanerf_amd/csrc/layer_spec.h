@@ -59,4 +59,16 @@ constexpr unsigned layer_offset(int l)
     return o;
 }
 
+// ---- split-bf16 ("bf16x3") stream: W = W_hi + W_lo (two bf16), one k-step of v_mfma_f32_32x32x16_bf16 covers 8 consecutive
+// k-pairs of the fp32 ordering (lane half h supplies its 8 channels), three products per step: W_hi X_hi + W_hi X_lo + W_lo X_hi.
+// Layout of a layer: uint32 [S = ceil(T/8)][NB][2 (hi, lo)][64 lanes][4] -- each (step, block, part) is one coalesced 1 KB load.
+constexpr int steps_b(int l) { return (kT[l] + 7) / 8; }
+constexpr unsigned layer_dwords_b(int l) { return (unsigned)steps_b(l) * (unsigned)kNB[l] * 2u * 64u * 4u; }
+constexpr unsigned layer_offset_b(int l)
+{
+    unsigned o = 0;
+    for (int i = 0; i < l; ++i) o += layer_dwords_b(i);
+    return o;
+}
+
 } // namespace vanerf

@@ -6,7 +6,7 @@
 // a sample split every K dimension between them (half h = l >> 5), see layer_spec.h.  All 20 dense
 // layers run as v_mfma_f32_32x32x2_f32 chains whose accumulators stay in registers from the
 // bilinear gathers to the final (alpha, sdf, rgb) store: activations never touch LDS or HBM.
-// LDS holds only the key points (positional encoding); the 1-NN vertex index arrives from vanerf_mesh_query_accel.
+// No LDS at all: key points come through the scalar cache; the 1-NN vertex index arrives from vanerf_mesh_query_accel.
 // Weights stream from L2 as pre-permuted MFMA A-fragments (weights_pack.cpp).
 //
 // Built with -ffp-contract=off: the integer-valued outputs (1-NN index) depend on fp32 compare
@@ -22,6 +22,15 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
 
+// Waves per SIMD of the split-bf16 kernel.  ONE, enforced by the register budget (__launch_bounds__(256, 1) gives the wave 512
+// registers, so a second wave cannot become resident): with two of these waves on a SIMD the kernel's results were not
+// reproducible run to run -- about 1e-3 of the 32-sample groups, always the last 16 lanes of the wave, first visible in
+// long-lived VGPRs (the gathered pixel features) -- while one wave per SIMD is bit-reproducible and matches the fp32-MFMA
+// kernel to 3.3e-5 on 10.9 M samples (tools/check_mode1_determinism.py).  The fp32-MFMA kernel never showed it at two waves.
+// Cause not isolated; the second wave was worth 5 % here, so it is not used.
+#ifndef VANERF_WAVES_PER_SIMD_B
+#define VANERF_WAVES_PER_SIMD_B 1
+#endif
 #ifndef VANERF_WAVES_PER_SIMD
 #define VANERF_WAVES_PER_SIMD 2
 #endif
@@ -30,6 +39,7 @@ constexpr int BLOCK = 64 * WAVES_PER_BLOCK;
 
 // Diagnostic build only (-DVANERF_STAMPS): per-phase s_memtime deltas summed per wave into QueryParams::stamps.
 // No stamp executes in the product build; stamp values never reach an output element.
+
 #ifdef VANERF_STAMPS
 #define STAMP(k)                                                                                  \
     do {                                                                                          \
@@ -61,6 +71,7 @@ struct QueryParams {
     unsigned long long* stamps; // [waves][N_PHASES] (diagnostic build), else unused
     unsigned* queue;            // work-queue head: next unclaimed 32-sample group (zero before the launch)
     unsigned long long* short_groups; // optional: += number of groups that took the all-invalid short path
+    float wm1[4], hm1[4];             // (float)(W - 1), (float)(H - 1) of the image / tex / geo0 / geo1 maps (kept scalar: no per-lane copies)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -149,6 +160,112 @@ __device__ __forceinline__ void run_layer(f32x16 (&acc)[NB], Ring<NB>& ring, WRs
     });
 }
 
+// ---------------------------------------------------------------------------------------------
+// split-bf16 ("bf16x3") variant of the layer runner: W = W_hi + W_lo, X = X_hi + X_lo (bf16 each),
+// acc += W_hi X_hi + W_hi X_lo + W_lo X_hi on v_mfma_f32_32x32x16_bf16 (fp32 accumulate).  One bf16 k-step covers 8 consecutive
+// k-pairs of the fp32 ordering, so the accumulator -> operand chaining of layer_spec.h is unchanged.  Measured against the fp32
+// oracle the dropped W_lo X_lo term and the 16-bit operands cost 1.2e-5 absolute on the outputs (the fp32-MFMA path: 9e-6).
+// ---------------------------------------------------------------------------------------------
+// ring depths (steps in flight) for layers with 4/3, 1 and 2 output blocks; measured 8.54 / 8.56 / 8.65 ms for (3,6,3) / (4,4,4) / (2,4,2)
+#ifndef VANERF_RINGB_WIDE
+#define VANERF_RINGB_WIDE 3
+#endif
+#ifndef VANERF_RINGB_D1
+#define VANERF_RINGB_D1 6
+#endif
+#ifndef VANERF_RINGB_D2
+#define VANERF_RINGB_D2 3
+#endif
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+template <int NB> struct WFragB { u32x4 hi[NB], lo[NB]; };
+template <int NB> struct RingDepthB { static constexpr int value = NB == 1 ? VANERF_RINGB_D1 : (NB == 2 ? VANERF_RINGB_D2 : VANERF_RINGB_WIDE); };
+template <int NB> struct RingB { WFragB<NB> f[RingDepthB<NB>::value]; };
+
+// step_dw: dword offset of (step, block 0, hi) in the stream; vb = lane * 16 bytes
+template <int NB> __device__ __forceinline__ WFragB<NB> wload_b(WRsrc rs, unsigned step_dw, unsigned vb)
+{
+    WFragB<NB> r;
+#pragma unroll
+    for (int ob = 0; ob < NB; ++ob) {
+        r.hi[ob] = __builtin_amdgcn_raw_buffer_load_b128(rs, vb, (step_dw + (ob * 2 + 0) * 256) * 4u, 0);
+        r.lo[ob] = __builtin_amdgcn_raw_buffer_load_b128(rs, vb, (step_dw + (ob * 2 + 1) * 256) * 4u, 0);
+    }
+    return r;
+}
+
+template <int NB, int T> __device__ __forceinline__ RingB<NB> ring_start_b(WRsrc rs, unsigned sbase_dw, unsigned vb)
+{
+    constexpr int D = RingDepthB<NB>::value, S = (T + 7) / 8;
+    RingB<NB> r;
+    static_for<D>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        if constexpr (i < S) r.f[i] = wload_b<NB>(rs, sbase_dw + i * NB * 512, vb);
+    });
+    return r;
+}
+
+__device__ __forceinline__ unsigned pack_bf16(float a, float b)
+{
+    const bf16x2 v = {(__bf16)a, (__bf16)b}; // v_cvt_pk_bf16_f32 (round to nearest even)
+    return __builtin_bit_cast(unsigned, v);
+}
+
+struct NoPre { template <class C> __device__ __forceinline__ void operator()(C) const {} };
+
+// pre(integral_constant<int, s>) runs before the operands of bf16 step s are gathered (lazy producers, e.g. the positional encoding)
+template <int NB, int T, class Op, class Pre = NoPre>
+__device__ __forceinline__ void run_layer_b(f32x16 (&acc)[NB], RingB<NB>& ring, WRsrc rs, unsigned sbase_dw, unsigned vb, Op&& operand,
+                                            Pre&& pre = Pre{})
+{
+    constexpr int D = RingDepthB<NB>::value, S = (T + 7) / 8;
+    static_for<S>([&](auto sc) {
+        constexpr int s = decltype(sc)::value;
+        pre(sc);
+        float x[8];
+        static_for<8>([&](auto jc) {
+            constexpr int j = decltype(jc)::value, t = 8 * s + j;
+            if constexpr (t < T) x[j] = operand(std::integral_constant<int, t>{});
+            else x[j] = 0.0f;
+        });
+        u32x4 bh, bl;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const unsigned hpk = pack_bf16(x[2 * i], x[2 * i + 1]);
+            bh[i] = hpk;
+            bl[i] = pack_bf16(x[2 * i] - __uint_as_float(hpk << 16), x[2 * i + 1] - __uint_as_float(hpk & 0xffff0000u));
+        }
+        const WFragB<NB> a = ring.f[s % D];
+        if constexpr (s + D < S) ring.f[s % D] = wload_b<NB>(rs, sbase_dw + (s + D) * NB * 512, vb);
+        const bf16x8 xh = __builtin_bit_cast(bf16x8, bh), xl = __builtin_bit_cast(bf16x8, bl);
+#pragma unroll
+        for (int ob = 0; ob < NB; ++ob) {
+            const bf16x8 wh = __builtin_bit_cast(bf16x8, a.hi[ob]), wl = __builtin_bit_cast(bf16x8, a.lo[ob]);
+            acc[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xh, acc[ob], 0, 0, 0);
+            acc[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xl, acc[ob], 0, 0, 0);
+            acc[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, xh, acc[ob], 0, 0, 0);
+        }
+    });
+}
+
+// precision-mode dispatch: MODE 0 = fp32 MFMA (exact), MODE 1 = split-bf16 x3
+template <int MODE, int NB> struct RingSel { using type = Ring<NB>; };
+template <int NB> struct RingSel<1, NB> { using type = RingB<NB>; };
+
+template <int MODE, int NB, int T, int L> __device__ __forceinline__ typename RingSel<MODE, NB>::type ring_start_m(WRsrc rs, int lane)
+{
+    if constexpr (MODE == 0) return ring_start<NB, T>(rs, layer_offset(L), (unsigned)lane * NB * 4u);
+    else return ring_start_b<NB, T>(rs, layer_offset_b(L), (unsigned)lane * 16u);
+}
+
+template <int MODE, int NB, int T, int L, class Op>
+__device__ __forceinline__ void run_layer_m(f32x16 (&acc)[NB], typename RingSel<MODE, NB>::type& ring, WRsrc rs, int lane, Op&& operand)
+{
+    if constexpr (MODE == 0) run_layer<NB, T>(acc, ring, rs, layer_offset(L), (unsigned)lane * NB * 4u, static_cast<Op&&>(operand));
+    else run_layer_b<NB, T>(acc, ring, rs, layer_offset_b(L), (unsigned)lane * 16u, static_cast<Op&&>(operand));
+}
+
 template <int NB> __device__ __forceinline__ void zero(f32x16 (&acc)[NB])
 {
 #pragma unroll
@@ -200,12 +317,12 @@ struct Bilin {
     float w00, w01, w10, w11;
 };
 
-__device__ __forceinline__ Bilin bilin_setup(float x, float y, int H, int W)
+__device__ __forceinline__ Bilin bilin_setup(float x, float y, int H, int W, float wm1, float hm1)
 {
-    float ix = ((x + 1.0f) / 2.0f) * (float)(W - 1);
-    float iy = ((y + 1.0f) / 2.0f) * (float)(H - 1);
-    ix = fminf((float)(W - 1), fmaxf(ix, 0.0f));
-    iy = fminf((float)(H - 1), fmaxf(iy, 0.0f));
+    float ix = ((x + 1.0f) / 2.0f) * wm1;
+    float iy = ((y + 1.0f) / 2.0f) * hm1;
+    ix = fminf(wm1, fmaxf(ix, 0.0f));
+    iy = fminf(hm1, fmaxf(iy, 0.0f));
     float fx = floorf(ix), fy = floorf(iy);
     float wx1 = ix - fx, wx0 = (fx + 1.0f) - ix;
     float wy1 = iy - fy, wy0 = (fy + 1.0f) - iy;
@@ -258,8 +375,8 @@ template <int C4> __device__ __forceinline__ void load_row(const float* __restri
 // one GeoVisFusion scale (src/networks.py:83-94 / 96-104): gates, gated 2-layer MLP.
 //   HC = channels per lane half (32 for the 64-channel map, 4 for the 8-channel map), NBO = output blocks,
 //   NREG_MID = registers of the last hidden block that carry real channels
-template <int HC, int NBO, int NREG_MID, int l_at_a>
-__device__ __forceinline__ void geo_scale(WRsrc W, int lane, Ring<1>& ring_at,
+template <int MODE, int HC, int NBO, int NREG_MID, int l_at_a>
+__device__ __forceinline__ void geo_scale(WRsrc W, int lane, typename RingSel<MODE, 1>::type& ring_at,
                                           float (&pix)[HC], float (&nn)[HC], float (&tw)[HC], float s0, float s1,
                                           f32x16 (&outacc)[NBO])
 {
@@ -273,16 +390,15 @@ __device__ __forceinline__ void geo_scale(WRsrc W, int lane, Ring<1>& ring_at,
         else if constexpr (t == 3 * HC) return s0;
         else return s1;
     };
-    const unsigned v1 = (unsigned)lane * 4u, vo = (unsigned)lane * NBO * 4u; // byte offsets
     f32x16 at[1];
     zero<1>(at);
-    run_layer<1, TIN>(at, ring_at, W, layer_offset(l_at_a), v1, input);
-    Ring<1> r_gate = ring_start<1, 6>(W, layer_offset(l_at_a + 1), v1);
-    Ring<NBO> r_mid = ring_start<NBO, TIN>(W, layer_offset(l_at_a + 2), vo);
+    run_layer_m<MODE, 1, TIN, l_at_a>(at, ring_at, W, lane, input);
+    auto r_gate = ring_start_m<MODE, 1, 6, l_at_a + 1>(W, lane);
+    auto r_mid = ring_start_m<MODE, NBO, TIN, l_at_a + 2>(W, lane);
     relu<1>(at);
     f32x16 gate[1];
     zero<1>(gate);
-    run_layer<1, 6>(gate, r_gate, W, layer_offset(l_at_a + 1), v1, [&](auto tc) -> float { return at[0][decltype(tc)::value]; });
+    run_layer_m<MODE, 1, 6, l_at_a + 1>(gate, r_gate, W, lane, [&](auto tc) -> float { return at[0][decltype(tc)::value]; });
     // gates live in rows 0..2 = registers 0..2 of the h = 0 lanes
     const float a0 = __shfl(sigmoid_f(gate[0][0]), lane & 31);
     const float a1 = __shfl(sigmoid_f(gate[0][1]), lane & 31);
@@ -291,22 +407,20 @@ __device__ __forceinline__ void geo_scale(WRsrc W, int lane, Ring<1>& ring_at,
     for (int t = 0; t < HC; ++t) { pix[t] *= a0; nn[t] *= a1; tw[t] *= a2; }
     f32x16 mid[NBO];
     zero<NBO>(mid);
-    run_layer<NBO, TIN>(mid, r_mid, W, layer_offset(l_at_a + 2), vo, input);
-    Ring<NBO> r_out = ring_start<NBO, TOUT>(W, layer_offset(l_at_a + 3), vo);
+    run_layer_m<MODE, NBO, TIN, l_at_a + 2>(mid, r_mid, W, lane, input);
+    auto r_out = ring_start_m<MODE, NBO, TOUT, l_at_a + 3>(W, lane);
     relu<NBO>(mid);
     zero<NBO>(outacc);
-    run_layer<NBO, TOUT>(outacc, r_out, W, layer_offset(l_at_a + 3), vo,
+    run_layer_m<MODE, NBO, TOUT, l_at_a + 3>(outacc, r_out, W, lane,
                          [&](auto tc) -> float { constexpr int t = decltype(tc)::value; return mid[t / 16][t % 16]; });
 }
 
-__global__ __launch_bounds__(BLOCK, VANERF_WAVES_PER_SIMD) void query_kernel(const QueryParams P)
+template <int MODE>
+__global__ __launch_bounds__(BLOCK, MODE == 1 ? VANERF_WAVES_PER_SIMD_B : VANERF_WAVES_PER_SIMD) void query_kernel(const QueryParams P)
 {
-    __shared__ float4 s_kpt[VANERF_NKPT];
-    for (int i = threadIdx.x; i < VANERF_NKPT; i += BLOCK) s_kpt[i] = reinterpret_cast<const float4*>(P.f.kpt_cam)[i];
-    __syncthreads();
 
     const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
-    const long long wave = (long long)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    [[maybe_unused]] const long long wave = (long long)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6); // STAMPS builds
     const long long ngroups = (P.n + 31) / 32;
     const VanerfFrame& F = P.f;
     const WRsrc W = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.w), 0, P.wbytes, 0x00020000); // kernarg-derived: wave-uniform
@@ -348,7 +462,7 @@ __global__ __launch_bounds__(BLOCK, VANERF_WAVES_PER_SIMD) void query_kernel(con
         float zn = 2.0f * (vz - F.znear) / (F.zfar - F.znear) - 1.0f;
         const float eps = 1e-2f;
         bool in_img = (x >= -1.0f - eps) && (x <= 1.0f + eps) && (y >= -1.0f - eps) && (y <= 1.0f + eps) && (zn >= -1.0f);
-        const Bilin bi = bilin_setup(x, y, F.hi, F.wi);
+        const Bilin bi = bilin_setup(x, y, F.hi, F.wi, P.wm1[0], P.hm1[0]);
         float fg = bilin_mix(bi, ld_off<float>(F.mask, 4u * bi.o00), ld_off<float>(F.mask, 4u * bi.o01), ld_off<float>(F.mask, 4u * bi.o10),
                               ld_off<float>(F.mask, 4u * bi.o11));
         const float mask = (in_img && fg > 0.1f) ? 1.0f : 0.0f;
@@ -374,7 +488,7 @@ __global__ __launch_bounds__(BLOCK, VANERF_WAVES_PER_SIMD) void query_kernel(con
         // ---- GeoVisFusion (src/networks.py:75-106) ---------------------------------------------------------
         // Every layer's fragment ring is started ahead of the previous layer's epilogue (see ring_start); the gathers of the
         // second scale and of the texture branch are issued here too, so their L2 latency hides behind the first layers.
-        const unsigned v1 = (unsigned)lane * 4u, v2 = (unsigned)lane * 8u, v3 = (unsigned)lane * 12u, v4 = (unsigned)lane * 16u; // byte offsets
+        [[maybe_unused]] const unsigned v4 = (unsigned)lane * 16u; // byte offset of the lane in a 4-block fp32 fragment
         // chain operand: register r of block b of a previous accumulator array, then the bias step
         auto chain = [&](auto& src, auto tc, auto nsteps) -> float {
             constexpr int t = decltype(tc)::value;
@@ -386,7 +500,7 @@ __global__ __launch_bounds__(BLOCK, VANERF_WAVES_PER_SIMD) void query_kernel(con
         auto tex_gathers = [&]() { // issued ~2 layers before the texture branch needs them
             load_row<8>(F.vfeat_tex, (unsigned)((h ? tw_idx : nn_idx) * 32), row);
             gather<1>(F.img, bi, 4, 0, qi);
-            const Bilin bt = bilin_setup(x, y, F.ht, F.wt);
+            const Bilin bt = bilin_setup(x, y, F.ht, F.wt, P.wm1[1], P.hm1[1]);
             gather<2>(F.tex, bt, 8, 0, qt);
         };
         f32x16 pool[4]; // [mean64 | var64]
@@ -397,31 +511,36 @@ __global__ __launch_bounds__(BLOCK, VANERF_WAVES_PER_SIMD) void query_kernel(con
         // (82 % of the MFMAs) are skipped -- same bits, wave-uniform branch.  With real foreground masks most samples are.
         const bool any_valid = __builtin_amdgcn_ballot_w64(mask > 0.0f) != 0ull;
         if (any_valid) {
-            Ring<1> r_at0 = ring_start<1, 98>(W, layer_offset(L_GEO_AT0_A), v1);
+            auto r_at0 = ring_start_m<MODE, 1, 98, L_GEO_AT0_A>(W, lane);
             f32x16 g64[2], g8[1];
             float pix8[4], nn8[4], tw8[4];
             {
                 float pix[32], nn[32], tw[32];
-                const Bilin b0 = bilin_setup(x, y, F.h0, F.w0);
+                const Bilin b0 = bilin_setup(x, y, F.h0, F.w0, P.wm1[2], P.hm1[2]);
                 gather<8>(F.geo0, b0, 64, 32 * h, pix);
                 load_row<8>(F.vfeat0, (unsigned)(nn_idx * 64 + 32 * h), nn);
                 load_row<8>(F.vfeat0, (unsigned)(tw_idx * 64 + 32 * h), tw);
-                const Bilin b1 = bilin_setup(x, y, F.h1, F.w1);
+                const Bilin b1 = bilin_setup(x, y, F.h1, F.w1, P.wm1[3], P.hm1[3]);
                 gather<1>(F.geo1, b1, 8, 4 * h, pix8);
                 load_row<1>(F.vfeat1, (unsigned)(nn_idx * 8 + 4 * h), nn8);
                 load_row<1>(F.vfeat1, (unsigned)(tw_idx * 8 + 4 * h), tw8);
                 STAMP(2); // geo gathers
-                geo_scale<32, 2, 16, L_GEO_AT0_A>(W, lane, r_at0, pix, nn, tw, sc0, sc1, g64);
+                geo_scale<MODE, 32, 2, 16, L_GEO_AT0_A>(W, lane, r_at0, pix, nn, tw, sc0, sc1, g64);
                 STAMP(3); // geo0 layers
             }
             // mlp0's ring (7 x dwordx4) starts before the small second scale runs
             constexpr unsigned base0 = layer_offset(L_MLP0);
             constexpr int D0 = PE_FEATS;
             WFrag<4> ring0[D0];
+            RingB<4> ring0b;
             {
-                Ring<1> r_at1 = ring_start<1, 14>(W, layer_offset(L_GEO_AT1_A), v1);
-                static_for<D0>([&](auto fc) { constexpr int f = decltype(fc)::value; ring0[f] = wload<4>(W, (base0 + f * 256) * 4u, v4); });
-                geo_scale<4, 1, 4, L_GEO_AT1_A>(W, lane, r_at1, pix8, nn8, tw8, sc0, sc1, g8);
+                auto r_at1 = ring_start_m<MODE, 1, 14, L_GEO_AT1_A>(W, lane);
+                if constexpr (MODE == 0) {
+                    static_for<D0>([&](auto fc) { constexpr int f = decltype(fc)::value; ring0[f] = wload<4>(W, (base0 + f * 256) * 4u, v4); });
+                } else {
+                    ring0b = ring_start_b<4, 180>(W, layer_offset_b(L_MLP0), (unsigned)lane * 16u);
+                }
+                geo_scale<MODE, 4, 1, 4, L_GEO_AT1_A>(W, lane, r_at1, pix8, nn8, tw8, sc0, sc1, g8);
                 STAMP(4); // geo1
             }
 
@@ -437,67 +556,96 @@ __global__ __launch_bounds__(BLOCK, VANERF_WAVES_PER_SIMD) void query_kernel(con
                     float cx = fmaf(pz, F.extrin[2], fmaf(py, F.extrin[1], px * F.extrin[0])) + F.extrin[3];
                     float cy = fmaf(pz, F.extrin[6], fmaf(py, F.extrin[5], px * F.extrin[4])) + F.extrin[7];
                     float cz = fmaf(pz, F.extrin[10], fmaf(py, F.extrin[9], px * F.extrin[8])) + F.extrin[11];
-                    const float4* kp = s_kpt + h * PE_KPT_PER_HALF;
-                    // fully unrolled: as a run-time loop hipcc hoists the seven prefetch loads of an iteration above its first use and
-                    // waits vmcnt(0) (no prefetch left), and copies the 64 accumulator registers around the back edge
-                    static_for<PE_KPT_PER_HALF>([&](auto ic) {
-                        constexpr int i = decltype(ic)::value;
-                        const float4 k = kp[i];
-                        const float ddx = cx - k.x, ddy = cy - k.y, ddz = cz - k.z;
+                    const float4* __restrict__ kpg = reinterpret_cast<const float4*>(F.kpt_cam);
+                    // the 7 positional-encoding features of key point i: dz, sin/cos(pi 2^l dz) for l = 0..2, all times the Gaussian decay.
+                    // v_sin_f32 / v_cos_f32 take revolutions, so the arguments are dz/2, dz, 2dz exactly (|error| < 1.6e-7 absolute over
+                    // the hand's extent, tools/probe_trig.hip)
+                    auto pe_features = [&](int i, float (&feat)[PE_FEATS]) {
+                        // key points through the scalar cache (wave-uniform addresses), selected per lane half.  No LDS in this
+                        // kernel: with two waves per SIMD an LDS return into a register that a just-issued (but queued) bf16 MFMA
+                        // still reads as its B operand corrupted columns 16..31 (tools/diag_mode1b.py).
+                        const float4 k0 = kpg[i], k1 = kpg[PE_KPT_PER_HALF + i];
+                        const float kx = h ? k1.x : k0.x, ky = h ? k1.y : k0.y, kz = h ? k1.z : k0.z;
+                        const float ddx = cx - kx, ddy = cy - ky, ddz = cz - kz;
                         const float d2 = (ddx * ddx + ddy * ddy) + ddz * ddz;
                         const float wk = __expf(-d2 * F.pe_inv_2sigma2);
                         const float dz = F.pe_scale * ddz;
-                        float feat[PE_FEATS];
-                        // sin/cos(pi 2^l dz): v_sin_f32 / v_cos_f32 take revolutions, so the arguments are dz/2, dz, 2dz exactly
-                        // (|error| < 1.6e-7 absolute over the hand's extent, tools/probe_trig.hip)
                         const float s0 = __builtin_amdgcn_sinf(0.5f * dz), c0 = __builtin_amdgcn_cosf(0.5f * dz);
                         const float s1 = __builtin_amdgcn_sinf(dz), c1 = __builtin_amdgcn_cosf(dz);
                         const float s2 = __builtin_amdgcn_sinf(2.0f * dz), c2 = __builtin_amdgcn_cosf(2.0f * dz);
                         feat[0] = dz * wk; feat[1] = s0 * wk; feat[2] = c0 * wk; feat[3] = s1 * wk; feat[4] = c1 * wk;
                         feat[5] = s2 * wk; feat[6] = c2 * wk;
-                        static_for<D0>([&](auto fc) {
-                            constexpr int f = decltype(fc)::value;
-                            const WFrag<4> a = ring0[f];
-                            // step 7(i+1)+f; after the last key point these are the first steps of the chain part below
-                            ring0[f] = wload<4>(W, (base0 + ((i + 1) * D0 + f) * 256) * 4u, v4);
-                            mfma_step<4>(a0, a, feat[f]);
+                    };
+                    if constexpr (MODE == 0) {
+                        // fully unrolled: as a run-time loop hipcc hoists the seven prefetch loads of an iteration above its first use and
+                        // waits vmcnt(0) (no prefetch left), and copies the 64 accumulator registers around the back edge
+                        static_for<PE_KPT_PER_HALF>([&](auto ic) {
+                            constexpr int i = decltype(ic)::value;
+                            float feat[PE_FEATS];
+                            pe_features(i, feat);
+                            static_for<D0>([&](auto fc) {
+                                constexpr int f = decltype(fc)::value;
+                                const WFrag<4> a = ring0[f];
+                                // step 7(i+1)+f; after the last key point these are the first steps of the chain part below
+                                ring0[f] = wload<4>(W, (base0 + ((i + 1) * D0 + f) * 256) * 4u, v4);
+                                mfma_step<4>(a0, a, feat[f]);
+                            });
                         });
-                    });
-                    constexpr unsigned nextp = base0 + (PE_KPT_PER_HALF + 1) * D0 * 256;
-                    // remaining 32 + 1 steps: geo64 (two blocks) and the bias; ring slot = step % 7 (147 = 21 * 7)
-                    constexpr int TREM = 33;
-                    static_for<TREM>([&](auto tc) {
-                        constexpr int t = decltype(tc)::value;
-                        const float b = chain(g64, tc, std::integral_constant<int, 32>{});
-                        const WFrag<4> a = ring0[t % D0];
-                        if constexpr (t + D0 < TREM) ring0[t % D0] = wload<4>(W, (nextp + t * 256) * 4u, v4);
-                        mfma_step<4>(a0, a, b);
-                    });
+                        constexpr unsigned nextp = base0 + (PE_KPT_PER_HALF + 1) * D0 * 256;
+                        // remaining 32 + 1 steps: geo64 (two blocks) and the bias; ring slot = step % 7 (147 = 21 * 7)
+                        constexpr int TREM = 33;
+                        static_for<TREM>([&](auto tc) {
+                            constexpr int t = decltype(tc)::value;
+                            const float b = chain(g64, tc, std::integral_constant<int, 32>{});
+                            const WFrag<4> a = ring0[t % D0];
+                            if constexpr (t + D0 < TREM) ring0[t % D0] = wload<4>(W, (nextp + t * 256) * 4u, v4);
+                            mfma_step<4>(a0, a, b);
+                        });
+                    } else {
+                        // split-bf16: k-pairs 0..146 are the features (pair 7i+f = feature f of key point i), 147..178 the geo64 chain,
+                        // 179 the bias.  A bf16 step takes 8 consecutive pairs, so key point i is computed right before the first step
+                        // that needs it (at most two key points are live at a time).
+                        float feat[PE_KPT_PER_HALF][PE_FEATS];
+                        run_layer_b<4, 180>(a0, ring0b, W, layer_offset_b(L_MLP0), (unsigned)lane * 16u,
+                            [&](auto tc) -> float {
+                                constexpr int t = decltype(tc)::value;
+                                if constexpr (t < 147) return feat[t / 7][t % 7];
+                                else return chain(g64, std::integral_constant<int, t - 147>{}, std::integral_constant<int, 32>{});
+                            },
+                            [&](auto sc) {
+                                constexpr int s_ = decltype(sc)::value;
+                                constexpr int lo_k = s_ == 0 ? 0 : (8 * s_ - 1) / 7 + 1, hi_k = (8 * s_ + 7) / 7; // key points first needed by this step
+                                static_for<(hi_k < PE_KPT_PER_HALF ? hi_k : PE_KPT_PER_HALF - 1) - lo_k + 1 < 0 ? 0 : (hi_k < PE_KPT_PER_HALF ? hi_k : PE_KPT_PER_HALF - 1) - lo_k + 1>([&](auto dc) {
+                                    constexpr int i = lo_k + decltype(dc)::value;
+                                    pe_features(i, feat[i]);
+                                });
+                            });
+                    }
                 }
                 STAMP(5); // mlp0 (PE + geo64)
-                Ring<4> r1 = ring_start<4, 65>(W, layer_offset(L_MLP1), v4);
+                auto r1 = ring_start_m<MODE, 4, 65, L_MLP1>(W, lane);
                 softplus<4>(a0);
                 f32x16 a1[4];
                 zero<4>(a1);
-                run_layer<4, 65>(a1, r1, W, layer_offset(L_MLP1), v4, [&](auto tc) -> float { return chain(a0, tc, std::integral_constant<int, 64>{}); });
-                Ring<4> r2 = ring_start<4, 69>(W, layer_offset(L_MLP2), v4);
+                run_layer_m<MODE, 4, 65, L_MLP1>(a1, r1, W, lane, [&](auto tc) -> float { return chain(a0, tc, std::integral_constant<int, 64>{}); });
+                auto r2 = ring_start_m<MODE, 4, 69, L_MLP2>(W, lane);
                 softplus<4>(a1);
                 zero<4>(a0);
-                run_layer<4, 69>(a0, r2, W, layer_offset(L_MLP2), v4, [&](auto tc) -> float {
+                run_layer_m<MODE, 4, 69, L_MLP2>(a0, r2, W, lane, [&](auto tc) -> float {
                     constexpr int t = decltype(tc)::value;
                     if constexpr (t < 64) return a1[t / 16][t % 16];
                     else if constexpr (t < 68) return g8[0][t - 64];
                     else return one_h0;
                 });
-                Ring<2> r3 = ring_start<2, 61>(W, layer_offset(L_MLP3), v2);
+                auto r3 = ring_start_m<MODE, 2, 61, L_MLP3>(W, lane);
                 softplus<4>(a0);
                 zero<2>(xv);
-                run_layer<2, 61>(xv, r3, W, layer_offset(L_MLP3), v2, [&](auto tc) -> float { return chain(a0, tc, std::integral_constant<int, 60>{}); });
+                run_layer_m<MODE, 2, 61, L_MLP3>(xv, r3, W, lane, [&](auto tc) -> float { return chain(a0, tc, std::integral_constant<int, 60>{}); });
             }
             STAMP(6); // softplus x3 + mlp1..3
             tex_gathers();
             // ---- PoolModule mean/var over V = 1 views (src/utils.py:744-779, 854-880) --------------------------
-            Ring<2> rh0 = ring_start<2, 65>(W, layer_offset(L_HEAD0), v2);
+            auto rh0 = ring_start_m<MODE, 2, 65, L_HEAD0>(W, lane);
     #pragma unroll
             for (int b = 0; b < 2; ++b)
     #pragma unroll
@@ -511,15 +659,15 @@ __global__ __launch_bounds__(BLOCK, VANERF_WAVES_PER_SIMD) void query_kernel(con
             {
                 f32x16 m0[2], m1[2];
                 zero<2>(m0);
-                run_layer<2, 65>(m0, rh0, W, layer_offset(L_HEAD0), v2, [&](auto tc) -> float { return chain(pool, tc, std::integral_constant<int, 64>{}); });
-                Ring<2> rh1 = ring_start<2, 33>(W, layer_offset(L_HEAD1), v2);
+                run_layer_m<MODE, 2, 65, L_HEAD0>(m0, rh0, W, lane, [&](auto tc) -> float { return chain(pool, tc, std::integral_constant<int, 64>{}); });
+                auto rh1 = ring_start_m<MODE, 2, 33, L_HEAD1>(W, lane);
                 softplus<2>(m0);
                 zero<2>(m1);
-                run_layer<2, 33>(m1, rh1, W, layer_offset(L_HEAD1), v2, [&](auto tc) -> float { return chain(m0, tc, std::integral_constant<int, 32>{}); });
-                Ring<1> rh2 = ring_start<1, 33>(W, layer_offset(L_HEAD2), v1);
+                run_layer_m<MODE, 2, 33, L_HEAD1>(m1, rh1, W, lane, [&](auto tc) -> float { return chain(m0, tc, std::integral_constant<int, 32>{}); });
+                auto rh2 = ring_start_m<MODE, 1, 33, L_HEAD2>(W, lane);
                 softplus<2>(m1);
                 zero<1>(head);
-                run_layer<1, 33>(head, rh2, W, layer_offset(L_HEAD2), v1, [&](auto tc) -> float { return chain(m1, tc, std::integral_constant<int, 32>{}); });
+                run_layer_m<MODE, 1, 33, L_HEAD2>(head, rh2, W, lane, [&](auto tc) -> float { return chain(m1, tc, std::integral_constant<int, 32>{}); });
             }
         } else {
             tex_gathers();
@@ -527,13 +675,13 @@ __global__ __launch_bounds__(BLOCK, VANERF_WAVES_PER_SIMD) void query_kernel(con
             zero<1>(head);
             if (lane == 0) ++short_groups;
         }
-        Ring<1> r_ibr = ring_start<1, 65>(W, layer_offset(L_IBR), v1);
+        auto r_ibr = ring_start_m<MODE, 1, 65, L_IBR>(W, lane);
         STAMP(7); // pool + head
         // ---- ibr_compress_gfeat 128 -> 24 (src/model.py:921) ------------------------------------------------
-        Ring<3> r_ta = ring_start<3, 49>(W, layer_offset(L_TEX_AT_A), v3);
+        auto r_ta = ring_start_m<MODE, 3, 49, L_TEX_AT_A>(W, lane);
         f32x16 lat[1];
         zero<1>(lat);
-        run_layer<1, 65>(lat, r_ibr, W, layer_offset(L_IBR), v1, [&](auto tc) -> float { return chain(pool, tc, std::integral_constant<int, 64>{}); });
+        run_layer_m<MODE, 1, 65, L_IBR>(lat, r_ibr, W, lane, [&](auto tc) -> float { return chain(pool, tc, std::integral_constant<int, 64>{}); });
         STAMP(8); // ibr
         // ---- TexVisFusion per-sample part (src/networks.py:281-293) -----------------------------------------
         f32x16 rgb[1];
@@ -555,13 +703,13 @@ __global__ __launch_bounds__(BLOCK, VANERF_WAVES_PER_SIMD) void query_kernel(con
             auto from_ta = [&](auto& ta_) { return [&](auto tc) -> float { constexpr int t = decltype(tc)::value; return ta_[t / 16][t % 16]; }; };
             f32x16 ta[3];
             zero<3>(ta);
-            run_layer<3, 49>(ta, r_ta, W, layer_offset(L_TEX_AT_A), v3, tex_in);
-            Ring<1> r_tg = ring_start<1, 48>(W, layer_offset(L_TEX_AT_B), v1);
+            run_layer_m<MODE, 3, 49, L_TEX_AT_A>(ta, r_ta, W, lane, tex_in);
+            auto r_tg = ring_start_m<MODE, 1, 48, L_TEX_AT_B>(W, lane);
             relu<3>(ta);
             f32x16 tg[1];
             zero<1>(tg);
-            run_layer<1, 48>(tg, r_tg, W, layer_offset(L_TEX_AT_B), v1, from_ta(ta));
-            Ring<3> r_tb = ring_start<3, 49>(W, layer_offset(L_TEX_A), v3);
+            run_layer_m<MODE, 1, 48, L_TEX_AT_B>(tg, r_tg, W, lane, from_ta(ta));
+            auto r_tb = ring_start_m<MODE, 3, 49, L_TEX_A>(W, lane);
             // six gates: rows 0..3 -> h = 0 lanes regs 0..3, rows 4,5 -> h = 1 lanes regs 0,1
             float m0 = sigmoid_f(tg[0][0]), m1 = sigmoid_f(tg[0][1]), m2 = sigmoid_f(tg[0][2]), m3 = sigmoid_f(tg[0][3]);
             float o0 = __shfl_xor(m0, 32), o1 = __shfl_xor(m1, 32), o2 = __shfl_xor(m2, 32);
@@ -578,11 +726,11 @@ __global__ __launch_bounds__(BLOCK, VANERF_WAVES_PER_SIMD) void query_kernel(con
 #pragma unroll
             for (int r = 0; r < 12; ++r) latg[r] = lat[0][r] * glat;
             zero<3>(ta);
-            run_layer<3, 49>(ta, r_tb, W, layer_offset(L_TEX_A), v3, tex_in);
-            Ring<1> r_rgb = ring_start<1, 48>(W, layer_offset(L_TEX_B), v1);
+            run_layer_m<MODE, 3, 49, L_TEX_A>(ta, r_tb, W, lane, tex_in);
+            auto r_rgb = ring_start_m<MODE, 1, 48, L_TEX_B>(W, lane);
             relu<3>(ta);
             zero<1>(rgb);
-            run_layer<1, 48>(rgb, r_rgb, W, layer_offset(L_TEX_B), v1, from_ta(ta));
+            run_layer_m<MODE, 1, 48, L_TEX_B>(rgb, r_rgb, W, lane, from_ta(ta));
         }
         STAMP(9); // tex
         // ---- eval_func (src/model.py:1140-1160): rows 0,1 of the head / 0..2 of the colour live in the h = 0 lanes ----
@@ -628,6 +776,9 @@ extern "C" int vanerf_query_samples(const VanerfWeights* w, const VanerfFrame* f
         QueryParams P;
         P.f = f; P.w = w->dev; P.wbytes = (unsigned)(w->n_floats * sizeof(float)); P.pts = pts; P.qsdf = query_sdf; P.qvis = query_vis; P.noise = noise; P.knn_in = knn_idx; P.raw = raw;
         P.n = n; P.out = out; P.valid = valid; P.stamps = nullptr; P.short_groups = w->stats;
+        { const int ws[4] = {P.f.wi, P.f.wt, P.f.w0, P.f.w1}, hs[4] = {P.f.hi, P.f.ht, P.f.h0, P.f.h1};
+          for (int i = 0; i < 4; ++i) { P.wm1[i] = (float)(ws[i] - 1); P.hm1[i] = (float)(hs[i] - 1); } }
+       
         long long ngroups = (n + 31) / 32;
         long long blocks = (ngroups + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
         int dev = 0, cus = 256;
@@ -636,14 +787,15 @@ extern "C" int vanerf_query_samples(const VanerfWeights* w, const VanerfFrame* f
         // Two 4-wave blocks per CU = two waves per SIMD (256 VGPRs each).  fp32 MFMA and fp32 VALU do not overlap on gfx950
         // (tools/probe_mfma_valu.hip: every VALU instruction adds its issue cycles to the MFMA time), so the second wave does not
         // hide VALU work behind MFMAs; what it hides is load latency and the in-order issue gaps of its partner.
-        int per_cu = 2;
+        int per_cu = w->mode == 1 ? VANERF_WAVES_PER_SIMD_B : 2;
         if (const char* e = getenv("VANERF_BLOCKS_PER_CU")) per_cu = atoi(e) > 0 ? atoi(e) : 2; // experiment knob
         long long cap = (long long)cus * per_cu;
         if (blocks > cap) blocks = cap;
         VanerfWeights* wm = const_cast<VanerfWeights*>(w);
         P.queue = wm->queues + (wm->next_queue++ % VanerfWeights::N_QUEUES);
         HIP_CHECK(hipMemsetAsync(P.queue, 0, sizeof(unsigned), (hipStream_t)stream));
-        hipLaunchKernelGGL(query_kernel, dim3((unsigned)blocks), dim3(BLOCK), 0, (hipStream_t)stream, P);
+        if (w->mode == 1) hipLaunchKernelGGL(query_kernel<1>, dim3((unsigned)blocks), dim3(BLOCK), 0, (hipStream_t)stream, P);
+        else hipLaunchKernelGGL(query_kernel<0>, dim3((unsigned)blocks), dim3(BLOCK), 0, (hipStream_t)stream, P);
         HIP_CHECK(hipGetLastError());
     });
 }
@@ -657,16 +809,19 @@ extern "C" int vanerf_debug_query_stamps(const VanerfWeights* w, const VanerfFra
         QueryParams P;
         P.f = *frame; P.w = w->dev; P.wbytes = (unsigned)(w->n_floats * sizeof(float)); P.pts = pts; P.qsdf = query_sdf; P.qvis = query_vis; P.noise = nullptr; P.knn_in = knn_idx; P.raw = 0;
         P.n = n; P.out = out; P.valid = nullptr; P.stamps = stamps; P.short_groups = nullptr;
+        { const int ws[4] = {P.f.wi, P.f.wt, P.f.w0, P.f.w1}, hs[4] = {P.f.hi, P.f.ht, P.f.h0, P.f.h1};
+          for (int i = 0; i < 4; ++i) { P.wm1[i] = (float)(ws[i] - 1); P.hm1[i] = (float)(hs[i] - 1); } }
         long long ngroups = (n + 31) / 32;
         long long blocks = (ngroups + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
-        long long capd = 512;
+        long long capd = w->mode == 1 ? 256LL * VANERF_WAVES_PER_SIMD_B : 512;
         if (const char* e = getenv("VANERF_BLOCKS_PER_CU")) capd = 256LL * (atoi(e) > 0 ? atoi(e) : 2);
         if (blocks > capd) blocks = capd;
         *n_waves = (int)blocks * WAVES_PER_BLOCK;
         VanerfWeights* wm = const_cast<VanerfWeights*>(w);
         P.queue = wm->queues + (wm->next_queue++ % VanerfWeights::N_QUEUES);
         HIP_CHECK(hipMemsetAsync(P.queue, 0, sizeof(unsigned), (hipStream_t)stream));
-        if (stamps) hipLaunchKernelGGL(query_kernel, dim3((unsigned)blocks), dim3(BLOCK), 0, (hipStream_t)stream, P);
+        if (stamps && w->mode == 1) hipLaunchKernelGGL(query_kernel<1>, dim3((unsigned)blocks), dim3(BLOCK), 0, (hipStream_t)stream, P);
+        else if (stamps) hipLaunchKernelGGL(query_kernel<0>, dim3((unsigned)blocks), dim3(BLOCK), 0, (hipStream_t)stream, P);
         HIP_CHECK(hipGetLastError());
     });
 }

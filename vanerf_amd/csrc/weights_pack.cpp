@@ -83,6 +83,50 @@ void emit(std::vector<float>& out, int layer, const Mat& m, const Pairs& pairs)
         }
 }
 
+inline unsigned short bf16_rne(float f)
+{
+    unsigned u;
+    std::memcpy(&u, &f, 4);
+    return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+inline float bf16_to_f32(unsigned short b)
+{
+    unsigned u = (unsigned)b << 16;
+    float f;
+    std::memcpy(&f, &u, 4);
+    return f;
+}
+
+// bf16x3 stream of one layer (layer_spec.h): element j of the 8-element fragment of lane (r, h) at step s is k-pair 8s + j
+void emit_b(std::vector<float>& out, int layer, const Mat& m, const Pairs& pairs)
+{
+    const int nb = kNB[layer], T = kT[layer], S = steps_b(layer);
+    if ((int)pairs.size() != T) throw_error("internal: layer %d has %d k-pairs, spec says %d", layer, (int)pairs.size(), T);
+    size_t base = out.size();
+    out.resize(base + layer_dwords_b(layer), 0.0f);
+    unsigned* dst = reinterpret_cast<unsigned*>(out.data() + base);
+    for (int s = 0; s < S; ++s)
+        for (int ob = 0; ob < nb; ++ob)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int o = ob * 32 + (lane & 31);
+                unsigned short hi[8] = {}, lo[8] = {};
+                for (int j = 0; j < 8; ++j) {
+                    const int t = 8 * s + j;
+                    if (t >= T || o >= m.nout) continue;
+                    const int k = (lane >> 5) ? pairs[t].second : pairs[t].first;
+                    if (k == ZERO) continue;
+                    const float v = (k == BIAS) ? (m.b.empty() ? 0.0f : m.b[o]) : m.w[(size_t)o * m.kin + k];
+                    hi[j] = bf16_rne(v);
+                    lo[j] = bf16_rne(v - bf16_to_f32(hi[j]));
+                }
+                for (int part = 0; part < 2; ++part) {
+                    const unsigned short* e = part ? lo : hi;
+                    unsigned* q = dst + ((((size_t)s * nb + ob) * 2 + part) * 64 + lane) * 4;
+                    for (int i = 0; i < 4; ++i) q[i] = (unsigned)e[2 * i] | ((unsigned)e[2 * i + 1] << 16);
+                }
+            }
+}
+
 // [pix | nn | twin] each `c` channels split in halves between the lane halves, then (sdf|qvis), (vis_nn|vis_twin)
 Pairs geo_input_pairs(int c)
 {
@@ -112,13 +156,15 @@ Pairs tex_input_pairs()
 
 namespace vanerf {
 
-void pack_weights_host(const VanerfWeightTable& w, std::vector<float>& out, LayerOffsets& offs)
+void pack_weights_host(const VanerfWeightTable& w, std::vector<float>& out, LayerOffsets& offs, int mode)
 {
     out.clear();
     auto begin = [&](int l) {
         offs.off[l] = (unsigned)out.size();
-        if (offs.off[l] != layer_offset(l)) throw_error("internal: layer %d starts at %u, layer_spec.h says %u", l, offs.off[l], layer_offset(l));
+        const unsigned want = mode ? layer_offset_b(l) : layer_offset(l);
+        if (offs.off[l] != want) throw_error("internal: layer %d starts at %u, layer_spec.h says %u", l, offs.off[l], want);
     };
+    auto put = [&](std::vector<float>& o, int l, const Mat& m, const Pairs& p) { mode ? emit_b(o, l, m, p) : emit(o, l, m, p); };
 
     // ---- GeoVisFusion (src/networks.py:75-106) ------------------------------------------------
     {
@@ -126,14 +172,14 @@ void pack_weights_host(const VanerfWeightTable& w, std::vector<float>& out, Laye
         chain(b10, 1, 6, 0, 10);
         chain(c2, 2, 16, 0, 64);
         chain(c1, 1, 4, 0, 8);
-        begin(L_GEO_AT0_A);   emit(out, L_GEO_AT0_A, plain(w.geo_at0_w1, nullptr, 10, 196), in0);
-        begin(L_GEO_AT0_B);   emit(out, L_GEO_AT0_B, plain(w.geo_at0_w2, nullptr, 3, 10), b10);
-        begin(L_GEO_ATED0_A); emit(out, L_GEO_ATED0_A, plain(w.geo_ated0_w1, nullptr, 64, 196), in0);
-        begin(L_GEO_ATED0_B); emit(out, L_GEO_ATED0_B, plain(w.geo_ated0_w2, nullptr, 64, 64), c2);
-        begin(L_GEO_AT1_A);   emit(out, L_GEO_AT1_A, plain(w.geo_at1_w1, nullptr, 10, 28), in1);
-        begin(L_GEO_AT1_B);   emit(out, L_GEO_AT1_B, plain(w.geo_at1_w2, nullptr, 3, 10), b10);
-        begin(L_GEO_ATED1_A); emit(out, L_GEO_ATED1_A, plain(w.geo_ated1_w1, nullptr, 8, 28), in1);
-        begin(L_GEO_ATED1_B); emit(out, L_GEO_ATED1_B, plain(w.geo_ated1_w2, nullptr, 8, 8), c1);
+        begin(L_GEO_AT0_A);   put(out, L_GEO_AT0_A, plain(w.geo_at0_w1, nullptr, 10, 196), in0);
+        begin(L_GEO_AT0_B);   put(out, L_GEO_AT0_B, plain(w.geo_at0_w2, nullptr, 3, 10), b10);
+        begin(L_GEO_ATED0_A); put(out, L_GEO_ATED0_A, plain(w.geo_ated0_w1, nullptr, 64, 196), in0);
+        begin(L_GEO_ATED0_B); put(out, L_GEO_ATED0_B, plain(w.geo_ated0_w2, nullptr, 64, 64), c2);
+        begin(L_GEO_AT1_A);   put(out, L_GEO_AT1_A, plain(w.geo_at1_w1, nullptr, 10, 28), in1);
+        begin(L_GEO_AT1_B);   put(out, L_GEO_AT1_B, plain(w.geo_at1_w2, nullptr, 3, 10), b10);
+        begin(L_GEO_ATED1_A); put(out, L_GEO_ATED1_A, plain(w.geo_ated1_w1, nullptr, 8, 28), in1);
+        begin(L_GEO_ATED1_B); put(out, L_GEO_ATED1_B, plain(w.geo_ated1_w2, nullptr, 8, 8), c1);
     }
     // ---- MLPUNetFusion (src/utils.py:633-649, 822-852) ------------------------------------------
     {
@@ -142,31 +188,31 @@ void pack_weights_host(const VanerfWeightTable& w, std::vector<float>& out, Laye
             for (int f = 0; f < PE_FEATS; ++f) p0.emplace_back(f * 42 + i, f * 42 + PE_KPT_PER_HALF + i);
         chain(p0, 2, 16, 294, 64);
         bias_pair(p0);
-        begin(L_MLP0); emit(out, L_MLP0, weight_normed(w.l1_v[0], w.l1_g[0], w.l1_b[0], 128, 358), p0);
+        begin(L_MLP0); put(out, L_MLP0, weight_normed(w.l1_v[0], w.l1_g[0], w.l1_b[0], 128, 358), p0);
         Pairs p1; chain(p1, 4, 16, 0, 128); bias_pair(p1);
-        begin(L_MLP1); emit(out, L_MLP1, weight_normed(w.l1_v[1], w.l1_g[1], w.l1_b[1], 128, 128), p1);
+        begin(L_MLP1); put(out, L_MLP1, weight_normed(w.l1_v[1], w.l1_g[1], w.l1_b[1], 128, 128), p1);
         Pairs p2; chain(p2, 4, 16, 0, 128); chain(p2, 1, 4, 128, 8); bias_pair(p2);
-        begin(L_MLP2); emit(out, L_MLP2, weight_normed(w.l1_v[2], w.l1_g[2], w.l1_b[2], 120, 136), p2);
+        begin(L_MLP2); put(out, L_MLP2, weight_normed(w.l1_v[2], w.l1_g[2], w.l1_b[2], 120, 136), p2);
         Pairs p3; chain(p3, 4, 12, 0, 120); bias_pair(p3);
-        begin(L_MLP3); emit(out, L_MLP3, plain(w.l1_w3, w.l1_b3, 64, 120), p3);
+        begin(L_MLP3); put(out, L_MLP3, plain(w.l1_w3, w.l1_b3, 64, 120), p3);
         Pairs pool; chain(pool, 2, 16, 0, 64); chain(pool, 2, 16, 64, 64); bias_pair(pool); // [mean | var]
-        begin(L_HEAD0); emit(out, L_HEAD0, weight_normed(w.l2_v[0], w.l2_g[0], w.l2_b[0], 64, 128), pool);
+        begin(L_HEAD0); put(out, L_HEAD0, weight_normed(w.l2_v[0], w.l2_g[0], w.l2_b[0], 64, 128), pool);
         Pairs h1; chain(h1, 2, 16, 0, 64); bias_pair(h1);
-        begin(L_HEAD1); emit(out, L_HEAD1, weight_normed(w.l2_v[1], w.l2_g[1], w.l2_b[1], 64, 64), h1);
-        begin(L_HEAD2); emit(out, L_HEAD2, plain(w.l2_w2, w.l2_b2, 2, 64), h1);
-        begin(L_IBR);   emit(out, L_IBR, plain(w.ibr_w, w.ibr_b, 24, 128), pool);
+        begin(L_HEAD1); put(out, L_HEAD1, weight_normed(w.l2_v[1], w.l2_g[1], w.l2_b[1], 64, 64), h1);
+        begin(L_HEAD2); put(out, L_HEAD2, plain(w.l2_w2, w.l2_b2, 2, 64), h1);
+        begin(L_IBR);   put(out, L_IBR, plain(w.ibr_w, w.ibr_b, 24, 128), pool);
     }
     // ---- TexVisFusion per-sample part (src/networks.py:281-293) -----------------------------------
     {
         Pairs in = tex_input_pairs(), c3;
         chain(c3, 3, 16, 0, 96);
-        begin(L_TEX_AT_A); emit(out, L_TEX_AT_A, plain(w.tex_at_w1, nullptr, 96, 96), in);
-        begin(L_TEX_AT_B); emit(out, L_TEX_AT_B, plain(w.tex_at_w2, nullptr, 6, 96), c3);
-        begin(L_TEX_A);    emit(out, L_TEX_A, plain(w.tex_w1, nullptr, 96, 96), in);
+        begin(L_TEX_AT_A); put(out, L_TEX_AT_A, plain(w.tex_at_w1, nullptr, 96, 96), in);
+        begin(L_TEX_AT_B); put(out, L_TEX_AT_B, plain(w.tex_at_w2, nullptr, 6, 96), c3);
+        begin(L_TEX_A);    put(out, L_TEX_A, plain(w.tex_w1, nullptr, 96, 96), in);
         // IBRRenderingHead at V = 1 returns rgb_feat[..., :3] exactly (src/model.py:1613, 1635): rows 0..2 of 40
-        begin(L_TEX_B);    emit(out, L_TEX_B, plain(w.tex_w2, nullptr, 3, 96), c3);
+        begin(L_TEX_B);    put(out, L_TEX_B, plain(w.tex_w2, nullptr, 3, 96), c3);
     }
-    // the kernel's two-deep fragment prefetch reads up to 2 k-steps (4 blocks wide) past a layer's end
+    // slack behind the last layer (prefetch rings never read past a layer's own steps, this is belt and braces)
     out.resize(out.size() + 2 * 64 * 4, 0.0f);
 }
 
