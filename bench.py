@@ -25,6 +25,8 @@ if REPO not in sys.path:
 FLOP_PER_SAMPLE = 2 * 143772          # 143 772 MAC per sample evaluation (V = 1)
 FLOP_PER_INVALID_SAMPLE = 2 * (3072 + 22848)  # ibr_compress + TexVisFusion only: all that an invalid sample needs
 PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_BF16_MFMA_TFLOPS = 2516.8        # MI355X_MICROARCH.md: ~2.5 PF dense bf16 (16 x the fp32 matrix rate)
+DEFAULT_PRECISION = "fp32"
 
 
 def usable_cores():
@@ -77,6 +79,8 @@ def main():
     ap.add_argument("--width", type=int, default=334)
     ap.add_argument("--samples", type=int, default=64)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo only for single-GPU rehearsals)")
+    ap.add_argument("--precision", choices=["fp32", "bf16x3"], default=DEFAULT_PRECISION,
+                    help="arithmetic of the per-sample dense layers: fp32 MFMA, or bf16 MFMA on split (hi + lo) operands with fp32 accumulate")
     ap.add_argument("--cpu-rays-side", type=int, default=64, help="cpu_baseline sample: side of the strided ray grid (0 = skip)")
     args = ap.parse_args()
 
@@ -106,7 +110,9 @@ def main():
     fd = synth.to_device(frame, "cuda")
     sdd = {k: v.cuda() for k, v in sd.items() if k.startswith("tex_vis_fusion.")}
     fdat = renderer.FrameData(sdd, fd["img_in"], fd["feat_geo"], fd["feat_tex"], fd["src_foreground_mask"], fd["cam_in"], fd["targets"], fd["sp_data"])
-    weights = renderer.PackedWeights(sd)
+    weights = renderer.PackedWeights(sd, mode=args.precision)
+    bf = args.precision == "bf16x3"
+    peak = PEAK_BF16_MFMA_TFLOPS if bf else PEAK_F32_MFMA_TFLOPS
     rows = shard_rows(H, world, rank)  # (y0, step, ny): interleaved rows -> even load
     events = []
 
@@ -164,14 +170,15 @@ def main():
     result = {
         "metric": "rendered rays/sec (64 samples/ray) + PSNR vs ref, 512x334 view", "value": rays_total * args.steps / dt, "unit": "rays/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
-        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "bf16x3 (bf16 MFMA on hi+lo split operands, f32 accumulate; outputs within 1e-4 of f32)" if bf else "f32", "data": "synthetic",
         "config": {"workload": f"configs/vanerf.json eval view {H}x{W}, {S} coarse + {S} importance samples/ray, "
                                "two-hand mesh 1558 verts / 3108 faces, 1 source view 256x256, random trained-like weights",
                    "network_evaluations_per_ray": {"reference": 3 * S, "executed": 2 * S,
                                                    "note": "fine composite re-uses the coarse evaluations (bit-identical, tests/test_hip_parity.py)"},
                    "rays": rays_total, "parallelism": f"rays{world}" if world > 1 else "single"},
-        "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
-                     "traffic": traffic, "traffic_unit": "HBM bytes per launch (FETCH_SIZE + WRITE_SIZE, profiles/r01_query_kernel_traffic.json)", "kernel": "query_kernel (v_mfma_f32_32x32x2_f32)", "launches": len(events),
+        "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                     "traffic": traffic, "traffic_unit": "HBM bytes per launch (FETCH_SIZE + WRITE_SIZE, profiles/r01_query_kernel_traffic.json)", "kernel": "query_kernel<1> (v_mfma_f32_32x32x16_bf16, 3 MFMA FLOPs executed per algorithmic FLOP)" if bf else "query_kernel<0> (v_mfma_f32_32x32x2_f32)", "launches": len(events),
                      "avg_launch_ms": statistics.mean(k_ms), "kernel_ms_per_step": sum(k_ms) / args.steps,
                      "flop_per_launch_avg": flops / len(events), "samples_per_launch_avg": sum(k_samples) / len(events),
                      "all_invalid_group_fraction": short_samples / max(1, sum(k_samples))},

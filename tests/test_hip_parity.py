@@ -247,6 +247,21 @@ def test_query_samples_split_bf16_vs_oracle(R, sd_full):
     assert err.max() <= TOL
 
 
+def test_split_bf16_matches_fp32_kernel_full_size(R, sd_full):
+    """All 10.9 M coarse samples of the benchmark view: the bf16x3 kernel stays within 1e-4 of the fp32-MFMA kernel on every output."""
+    frame = _frame(11, 512, 15.0, tar_w=334)
+    fdat = _frame_data(R, sd_full, frame)
+    rays = R.ray_setup(frame["cam_tar"], frame["bounds"], 0, 0, 1, 334, 512, 64, device="cuda")
+    pts = R.sample_points(rays["rays_d"], rays["cam_pos"], rays["z"])
+    q_sdf, q_vis, knn = R.mesh_query_accel(fdat.accel, fdat.verts3, fdat.faces, fdat.vert_vis, pts)
+    a, va = R.query_samples(R.PackedWeights(sd_full, mode="fp32"), fdat, pts, q_sdf, q_vis, knn, want_valid=True)
+    b, vb = R.query_samples(R.PackedWeights(sd_full, mode="bf16x3"), fdat, pts, q_sdf, q_vis, knn, want_valid=True)
+    assert torch.equal(va, vb)
+    err = (a - b).abs().max(0)[0]
+    print("bf16x3 vs fp32 kernel, max abs diff [alpha, sdf, r, g, b]:", err.tolist())
+    assert err.max() <= TOL
+
+
 def test_query_samples_vs_reference_golden(R, sd_full, golden):
     """Golden vector produced by the reference's own VANeRF.query (tests/golden/query.npz)."""
     g = golden("query")
@@ -264,12 +279,16 @@ def test_query_samples_vs_reference_golden(R, sd_full, golden):
 
 @pytest.mark.parametrize("tag,seed,hw,orbit,half", [("pass_8x8_s16", 3, 64, 8.0, False), ("pass_16x16_s24_bvv", 5, 64, 70.0, True),
                                                      ("pass_64x64_s64", 11, 256, 15.0, False)])
-def test_render_pass_vs_reference_golden(R, sd_full, golden, tag, seed, hw, orbit, half):
-    """Whole pass against the outputs of the reference's batch_render_pifu_nerf (tests/golden/pass_*.npz)."""
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_render_pass_vs_reference_golden(R, sd_full, golden, tag, seed, hw, orbit, half, precision):
+    """Whole pass against the outputs of the reference's batch_render_pifu_nerf (tests/golden/pass_*.npz), both MFMA precisions."""
     g = golden(tag)
     frame = _frame(seed, hw, orbit, half)
     fdat = _frame_data(R, sd_full, frame)
-    w = R.PackedWeights(sd_full)
+    w = R.PackedWeights(sd_full, mode=precision)
+    # the pixels above TOL are discrete flips (importance-sampling bin, arg-min vertex, mask threshold) triggered by last-bit
+    # differences; the bf16x3 kernel's 3e-5 (against 1e-5) triggers them about twice as often: 2 of the 256 pixels of the 16x16 case
+    outliers = OUTLIERS if precision == "fp32" else 2 * OUTLIERS
     S, level = int(g["S"]), int(g["level"])
     step = 2 ** (level - 1)
     off = g["stride_xy"].long().tolist()
@@ -278,38 +297,47 @@ def test_render_pass_vs_reference_golden(R, sd_full, golden, tag, seed, hw, orbi
     out = R.render_pass(w, fdat, cam, frame["bounds"], off[0], off[1], step, n, n, S, S)
     for k, gk in (("color", "tex_fg"), ("color_fine", "tex_fg_fine")):
         got = out[k].cpu().view(n, n, 3).permute(2, 0, 1)
-        err, bad = assert_close_frac(got, g[gk][0], TOL, OUTLIERS, gk)
+        err, bad = assert_close_frac(got, g[gk][0], TOL, outliers, gk)
         print(tag, gk, "max abs err", err, "outliers", bad, "psnr", orc.psnr(got, g[gk][0]))
     for k, gk in (("depth", "depth"), ("alpha", "alpha"), ("depth_fine", "depth_fine"), ("alpha_fine", "alpha_fine"), ("sdf", "sdf")):
-        assert_close_frac(out[k].cpu().view(n, n), g[gk][0], TOL, OUTLIERS, gk)
+        assert_close_frac(out[k].cpu().view(n, n), g[gk][0], TOL, outliers, gk)
     assert torch.equal(fdat.vert_vis.cpu(), g["vert_vis"][0, :, 0])
 
 
-def test_render_pass_vs_oracle_benchmark_shape(R, sd_full):
-    """A strided slice of the 512x334 @ 64+64 benchmark view against the oracle (the full view takes the oracle ~15 min)."""
+@pytest.fixture(scope="module")
+def oracle_benchmark_slice(sd_full):
+    """Oracle render of a strided slice of the 512x334 @ 64+64 benchmark view (the full view takes the oracle ~15 min)."""
     frame = _frame(11, 512, 15.0, tar_w=334)
-    fdat = _frame_data(R, sd_full, frame)
-    w = R.PackedWeights(sd_full)
     step, nx, ny = 16, 334 // 16, 512 // 16
-    out = R.render_pass(w, fdat, frame["cam_tar"], frame["bounds"], 5, 3, step, nx, ny, 64, 64)
     gy, gx = torch.meshgrid(torch.arange(ny) * step + 3, torch.arange(nx) * step + 5, indexing="ij")
     grids = torch.stack([gx, gy], -1).view(1, -1, 2)
     fr = dict(frame)
     fr["out_hw"] = (ny, nx)
-    ref = orc.batch_render(sd_full, fr, 1, None, 64, 64, grids=grids)
+    return frame, orc.batch_render(sd_full, fr, 1, None, 64, 64, grids=grids)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_render_pass_vs_oracle_benchmark_shape(R, sd_full, oracle_benchmark_slice, precision):
+    """A strided slice of the 512x334 @ 64+64 benchmark view against the oracle, both MFMA precisions."""
+    frame, ref = oracle_benchmark_slice
+    fdat = _frame_data(R, sd_full, frame)
+    w = R.PackedWeights(sd_full, mode=precision)
+    step, nx, ny = 16, 334 // 16, 512 // 16
+    out = R.render_pass(w, fdat, frame["cam_tar"], frame["bounds"], 5, 3, step, nx, ny, 64, 64)
     assert torch.equal(out["index"].cpu(), ref["index"][0])
     got = out["color_fine"].cpu().view(ny, nx, 3).permute(2, 0, 1)
     err, bad = assert_close_frac(got, ref["tex_fg_fine"][0], TOL, OUTLIERS, "tex_fg_fine")
-    print("512x334 slice: max abs err", err, "outliers", bad, "psnr", orc.psnr(got, ref["tex_fg_fine"][0]))
+    print(precision, "512x334 slice: max abs err", err, "outliers", bad, "psnr", orc.psnr(got, ref["tex_fg_fine"][0]))
     assert orc.psnr(got, ref["tex_fg_fine"][0]) > 80.0
     assert_close_frac(out["depth_fine"].cpu().view(ny, nx), ref["depth_fine"][0], TOL, OUTLIERS, "depth_fine")
 
 
-def test_full_view_properties(R, sd_full):
-    """Size-independent checks at the full benchmark size (512x334, 64+64 samples)."""
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_full_view_properties(R, sd_full, precision):
+    """Size-independent checks at the full benchmark size (512x334, 64+64 samples), both MFMA precisions."""
     frame = _frame(11, 512, 15.0, tar_w=334)
     fdat = _frame_data(R, sd_full, frame)
-    w = R.PackedWeights(sd_full)
+    w = R.PackedWeights(sd_full, mode=precision)
     full = R.render_pass(w, fdat, frame["cam_tar"], frame["bounds"], 0, 0, 1, 334, 512, 64, 64)
     torch.cuda.synchronize()
     assert full["color_fine"].shape == (334 * 512, 3) and torch.isfinite(full["color_fine"]).all()
@@ -317,9 +345,12 @@ def test_full_view_properties(R, sd_full):
     zf = full["z_fine"]
     assert (zf[:, 1:] >= zf[:, :-1]).all()  # sortedness
     assert (full["alpha_fine"] <= 1.0 + 1e-5).all() and (full["alpha_fine"] >= 0).all()
-    # determinism / idempotence: a second launch gives identical bits
-    again = R.render_pass(w, fdat, frame["cam_tar"], frame["bounds"], 0, 0, 1, 334, 512, 64, 64)
-    assert torch.equal(full["color_fine"], again["color_fine"])
+    # determinism / idempotence: later launches give identical bits (the bf16 kernel was NOT reproducible with two waves per
+    # SIMD -- csrc/query_kernel.hip, VANERF_WAVES_PER_SIMD_B -- so this is checked more than once)
+    for _ in range(3):
+        again = R.render_pass(w, fdat, frame["cam_tar"], frame["bounds"], 0, 0, 1, 334, 512, 64, 64)
+        for k in ("color_fine", "depth_fine", "alpha_fine", "sdf", "color"):
+            assert torch.equal(full[k], again[k]), k
     # re-using the coarse evaluations in the fine composite gives the same bits as evaluating all 128 samples again
     redo = R.render_pass(w, fdat, frame["cam_tar"], frame["bounds"], 0, 200, 1, 334, 32, 64, 64, reuse_coarse=False)
     for k in ("color_fine", "depth_fine", "alpha_fine", "sdf"):

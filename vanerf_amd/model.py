@@ -157,6 +157,7 @@ class VANeRF(nn.Module):
         self.feat_tex = None
         self.kwargs = model_cfg
         self.disable_bg = True
+        self.precision = model_cfg.get("mfma_precision", "fp32")  # "fp32" | "bf16x3" (renderer.PRECISIONS); not a reference key
         self._packed = None  # (version key, PackedWeights)
         self._frame_cache = None
 
@@ -206,8 +207,9 @@ class VANeRF(nn.Module):
         sd = self._hot_state()
         key = tuple((k, v._version, v.data_ptr()) for k, v in sd.items() if k.startswith(("geo_vis_fusion.", "mlp_geo.", "ibr_compress_gfeat.",
                                                                                          "tex_vis_fusion.fconv.", "tex_vis_fusion.fconv_at.", "sigmoid_beta")))
+        key = (self.precision,) + key
         if self._packed is None or self._packed[0] != key:
-            self._packed = (key, R.PackedWeights(sd))
+            self._packed = (key, R.PackedWeights(sd, mode=self.precision))
         return self._packed[1]
 
     def frame_data(self, img_in, cam_in, targets, feat_geo, feat_tex, sp_data, fg_mask):

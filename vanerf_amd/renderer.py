@@ -89,10 +89,21 @@ def weight_table(sd):
     return tab, keep
 
 
+# Arithmetic of the per-sample dense layers (vanerf_weights_pack `mode`, include/vanerf_hip.h):
+#   "fp32"   v_mfma_f32_32x32x2_f32 on the fp32 weights and activations (1e-5 of the fp32 oracle: summation order only)
+#   "bf16x3" v_mfma_f32_32x32x16_bf16 on weights and activations split into two bf16 parts each, three products, fp32
+#            accumulate (3e-5 of the "fp32" kernel on the outputs; about twice as fast)
+PRECISIONS = {"fp32": 0, "bf16x3": 1}
+
+
 class PackedWeights:
     """Device-resident MFMA-fragment copy of the per-sample network weights (vanerf_weights_pack)."""
 
     def __init__(self, sd, mode=0):
+        mode = PRECISIONS.get(mode, mode)
+        if mode not in (0, 1):
+            raise ValueError(f"precision must be one of {sorted(PRECISIONS)}")
+        self.mode = mode
         tab, keep = weight_table(sd)
         h = c_void_p()
         check(lib.vanerf_weights_pack(byref(tab), mode, byref(h)))
