@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define VANERF_ABI_VERSION 1
+#define VANERF_ABI_VERSION 2
 
 #define VANERF_OK 0
 #define VANERF_EINVAL (-22)
@@ -141,7 +141,9 @@ int vanerf_mesh_query(const float* verts, int nv, const int32_t* faces, int nf, 
  * vanerf_amd/renderer.py:MeshAccel).  Results are bit-identical to vanerf_mesh_query.                                   */
 typedef struct {
     const float* tri;          /* [nfp][9]  triangle corners, Morton-sorted, padded to a multiple of 16 with far-away triangles */
-    const float* sphere;       /* [nfp][4]  bounding sphere of each triangle (centre, radius) */
+    const float* sphere;       /* [nfp][4]  bounding sphere of each triangle (centroid, radius) */
+    const float* tnorm;        /* [nfp][4]  unit normal of each triangle (0 for a degenerate one), w = rounding allowance 1e5 a^2: with `sphere` the triangle lies in the
+                                *           disc {centroid + u : u normal to tnorm, |u| <= radius} -- the lower bound the search prunes with */
     const int32_t* orig;       /* [nfp]     original face index (INT32_MAX for padding) */
     const float* cbox;         /* [nc][6]   AABB of each cluster of 16 triangles (lo xyz, hi xyz) */
     int nfp, nc;

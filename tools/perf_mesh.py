@@ -24,3 +24,17 @@ for grid in ((334, 512, 64), None):
         torch.cuda.synchronize()
         ts.append(e0.elapsed_time(e1))
     print(f"grid hint {grid}: ms min {min(ts):.3f}  hit-bbox fraction {rays['hit'].float().mean().item():.3f}  inside {float((out[0] < 0).float().mean()):.4f}")
+
+if "--phases" in sys.argv:  # needs VANERF_HIPCC_FLAGS=-DVANERF_MESH_PHASES
+    import ctypes
+    from vanerf_amd._ffi import lib
+    buf = (ctypes.c_uint64 * 8)()
+    lib.vanerf_debug_mesh_phases.restype = ctypes.c_int
+    lib.vanerf_debug_mesh_phases(buf, 1)
+    R.mesh_query_accel(fdat.accel, fdat.verts3, fdat.faces, fdat.vert_vis, pts, grid=(334, 512, 64)); torch.cuda.synchronize()
+    lib.vanerf_debug_mesh_phases(buf, 1)
+    tot = sum(buf[:5])
+    for name, v in zip(["point load", "1-NN vertex", "closest face", "inside test", "visibility + stores"], buf):
+        print(f"  {name:20s} {100.0 * v / tot:5.1f} %  {v / (pts.shape[0] / 64):9.0f} cycles per 64 points")
+    nw = pts.shape[0] / 64
+    print(f"  per wave of 64 points: {buf[5] / nw:.1f} rounds of 4 clusters, {buf[6] / nw:.1f} candidate triangles, {buf[7] / nw:.1f} exact evaluations")

@@ -229,9 +229,20 @@ __global__ __launch_bounds__(256) void knn1_kernel(const float4* __restrict__ ve
 //     cell; the +x ray of a point can only cross triangles of its own cell.
 // The structure is built per source frame by vanerf_amd/renderer.py:MeshAccel (torch on the device).
 constexpr int CL = 16; // triangles per cluster
-constexpr int MA_BLOCK = 256;
+#ifndef VANERF_MA_BLOCK
+#define VANERF_MA_BLOCK 512
+#endif
+constexpr int MA_BLOCK = VANERF_MA_BLOCK;
 constexpr int MA_MAX_CLUSTERS = 4096;
 constexpr int MA_MAX_VCLUSTERS = 1024;
+
+// Diagnostic build only (-DVANERF_MESH_PHASES): s_memtime deltas per phase, summed over waves (tools/perf_mesh.py --phases)
+#ifdef VANERF_MESH_PHASES
+__device__ unsigned long long g_ma_phase[8];
+#define MPH(k) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ph[k] += t_ - tprev; tprev = t_; } while (0)
+#else
+#define MPH(k) do { } while (0)
+#endif
 
 __device__ __forceinline__ float box_dist2(f3 p, const float* b)
 {
@@ -247,7 +258,7 @@ __global__ __launch_bounds__(MA_BLOCK) void mesh_query_accel_kernel(const Vanerf
                                                                     uint8_t* __restrict__ vis, int32_t* __restrict__ face,
                                                                     int32_t* __restrict__ knn, int gnx, int gny, int gS)
 {
-    // dynamic LDS: [nc][6] triangle-cluster boxes | [nvc][6] vertex-cluster boxes | [nvc*16] sorted vertices (float4)
+    // dynamic LDS: [nvc*16] sorted vertices (float4) | [nvc][6] vertex-cluster boxes | [nc][6] triangle-cluster boxes
     extern __shared__ float4 s_dyn[];
     float4* s_vs = s_dyn;
     float* s_vbox = reinterpret_cast<float*>(s_vs + A.nvc * CL);
@@ -264,22 +275,50 @@ __global__ __launch_bounds__(MA_BLOCK) void mesh_query_accel_kernel(const Vanerf
     const long long wave0 = ((long long)blockIdx.x * MA_BLOCK + threadIdx.x) >> 6, nwaves = ((long long)gridDim.x * MA_BLOCK) >> 6;
     const int ntx = (gnx + 7) >> 3, nty = (gny + 7) >> 3;
     const long long nwork = gnx > 0 ? (long long)ntx * nty * gS : (n + 63) >> 6;
+#ifdef VANERF_MESH_PHASES
+    unsigned long long ph[8] = {}, tprev = __builtin_amdgcn_s_memtime();
+#endif
     for (long long w = wave0; w < nwork; w += nwaves) {
+        // every lane keeps a point (the searches below are wave-cooperative): a lane beyond the grid border / the end of the batch
+        // repeats a neighbour's point and does not store
         long long i;
+        bool act;
         if (gnx > 0) {
             const int d = (int)(w % gS);
             const long long tile = w / gS;
             const int tx = (int)(tile % ntx), ty = (int)(tile / ntx);
             const int rx = tx * 8 + (lane & 7), ry = ty * 8 + (lane >> 3);
-            if (rx >= gnx || ry >= gny) continue;
-            i = ((long long)ry * gnx + rx) * gS + d;
+            act = rx < gnx && ry < gny;
+            i = ((long long)min(ry, gny - 1) * gnx + min(rx, gnx - 1)) * gS + d;
         } else {
             i = w * 64 + lane;
-            if (i >= n) continue;
+            act = i < n;
+            i = act ? i : n - 1;
         }
         const f3 p = {P[3 * i], P[3 * i + 1], P[3 * i + 2]};
+        MPH(0); // point load
         // ---- 1-NN vertex (knn_points K=1, src/networks.py:28): clusters of 16 Morton-sorted vertices; squared distance
         //      ((dx*dx + dy*dy) + dz*dz), first minimum in ORIGINAL vertex order (oracle/mesh_oracle.c:knn1)
+        // Both searches prune per WAVE first: the 64 points of a wave lie in a small box T, and a cluster whose box is farther from
+        // T than the largest bound any lane holds cannot matter to any lane.  The lanes test 64 clusters at a time against T (one
+        // cluster per lane, __ballot), and only the surviving clusters are then tested by every lane against its own point and
+        // bound -- the flat per-lane loop over all boxes this replaces was 2/3 of the kernel's instructions.
+        float tlo[3] = {p.x, p.y, p.z}, thi[3] = {p.x, p.y, p.z};
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1)
+#pragma unroll
+            for (int a = 0; a < 3; ++a) { tlo[a] = fminf(tlo[a], __shfl_xor(tlo[a], m)); thi[a] = fmaxf(thi[a], __shfl_xor(thi[a], m)); }
+        auto tile_dist2 = [&](const float* b) { // box-to-box: <= box_dist2(q, b) for every q in T (same monotone fp32 expression)
+            const float dx = fmaxf(fmaxf(b[0] - thi[0], tlo[0] - b[3]), 0.0f);
+            const float dy = fmaxf(fmaxf(b[1] - thi[1], tlo[1] - b[4]), 0.0f);
+            const float dz = fmaxf(fmaxf(b[2] - thi[2], tlo[2] - b[5]), 0.0f);
+            return (dx * dx + dy * dy) + dz * dz;
+        };
+        auto wave_max = [&](float v) {
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m));
+            return v;
+        };
         float vb = INFINITY;
         int vi = 0x7fffffff;
         {
@@ -292,43 +331,98 @@ __global__ __launch_bounds__(MA_BLOCK) void mesh_query_accel_kernel(const Vanerf
                     if (d < vb || (d == vb && oi < vi)) { vb = d; vi = oi; }
                 }
             };
-            float vmin = INFINITY;
+            // seed: the vertex cluster nearest to the centre of T, evaluated by every lane
+            const f3 tc = {0.5f * (tlo[0] + thi[0]), 0.5f * (tlo[1] + thi[1]), 0.5f * (tlo[2] + thi[2])};
+            float smin = INFINITY;
             int cm = 0;
-            for (int c = 0; c < A.nvc; ++c) {
-                const float lb = box_dist2(p, s_vbox + 6 * c);
-                if (lb < vmin) { vmin = lb; cm = c; }
+            for (int c = lane; c < A.nvc; c += 64) {
+                const float lb = box_dist2(tc, s_vbox + 6 * c);
+                if (lb < smin) { smin = lb; cm = c; }
+            }
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) {
+                const float o = __shfl_xor(smin, m);
+                const int oc = __shfl_xor(cm, m);
+                if (o < smin || (o == smin && oc < cm)) { smin = o; cm = oc; }
             }
             eval_v(cm);
-            for (int c = 0; c < A.nvc; ++c) {
-                if (c == cm) continue;
-                if (box_dist2(p, s_vbox + 6 * c) > vb * (1.0f + 1e-4f) + 1e-12f) continue;
-                eval_v(c);
+            const float capw = wave_max(vb) * (1.0f + 1e-4f) + 1e-12f;
+            for (int c0 = 0; c0 < A.nvc; c0 += 64) {
+                const int cl_ = c0 + lane;
+                unsigned long long m = __ballot(cl_ < A.nvc && cl_ != cm && tile_dist2(s_vbox + 6 * min(cl_, A.nvc - 1)) <= capw);
+                while (m) {
+                    const int c = c0 + __builtin_ctzll(m);
+                    m &= m - 1;
+                    if (box_dist2(p, s_vbox + 6 * c) > vb * (1.0f + 1e-4f) + 1e-12f) continue;
+                    eval_v(c);
+                }
             }
-            if (knn) knn[i] = vi;
+            if (knn && act) knn[i] = vi;
         }
-        // ---- closest face (70 % of this kernel; dominated by samples far from the mesh, where hundreds of triangles are
-        //      nearly equidistant and survive any exact bound -- seeding `best` with the faces around the nearest vertex was
-        //      measured and changes nothing): the nearest vertex belongs to some triangle, so its distance bounds the closest-face distance
-        //      from above; a cluster / triangle whose lower bound exceeds min(best, that bound) by the safety margin cannot
-        //      hold the minimum or a tie.
+        MPH(1); // 1-NN
+        // ---- closest face.  The nearest vertex belongs to some triangle, so its distance bounds the closest-face distance from
+        //      above; a cluster / triangle whose LOWER bound exceeds min(best, that bound) by the safety margin cannot hold the
+        //      minimum or a tie.  Lower bounds: a triangle lies in the plane through its centroid c (unit normal n), within r of c,
+        //      so with e = p - c, h = n.e:  d^2 >= h^2 + max(0, sqrt(|e|^2 - h^2) - r)^2.  For a sample far from the mesh, where
+        //      hundreds of triangles are nearly equidistant from p, this keeps the few it is roughly above -- the bounding-sphere
+        //      bound (|e| - r)^2 it replaces kept every triangle of a patch of radius ~sqrt(2 d r) (5x the exact evaluations).
+        //      Rounding: n and the dot products are off by <= 1e-6 |e|, the stored centres by <= a = 1e-6 x (largest
+        //      coordinate) -- the radii are padded by a on the host -- so |h| is off by delta <= 1e-6 |e| + a and
+        //      h^2 by 2 |h| delta <= kappa |e|^2 + w with w = 1e5 a^2 (tnorm.w); h^2 is lowered by that much where it adds
+        //      to the bound and raised where it is subtracted.
+        constexpr float kappa = 3e-5f;
         float best = INFINITY;
         int bf = 0x7fffffff;
-        for (int c = 0; c < A.nc; ++c) {
-            const float cap = fminf(best, vb) * (1.0f + 1e-4f) + 1e-12f;
-            if (box_dist2(p, s_box + 6 * c) > cap) continue;
-            for (int k = 0; k < CL; ++k) {
-                const int t = c * CL + k;
-                const float4 sp = reinterpret_cast<const float4*>(A.sphere)[t];
-                const float ex = p.x - sp.x, ey = p.y - sp.y, ez = p.z - sp.z;
-                const float g = fmaxf(sqrtf((ex * ex + ey * ey) + ez * ez) - sp.w, 0.0f);
-                if (g * g > fminf(best, vb) * (1.0f + 1e-4f) + 1e-12f) continue;
-                const float* q = A.tri + (size_t)t * 9;
-                const f3 a = {q[0], q[1], q[2]}, b = {q[3], q[4], q[5]}, c3 = {q[6], q[7], q[8]};
-                const float d = point_tri_dist2(p, a, b, c3);
-                const int of = A.orig[t];
-                if (d < best || (d == best && of < bf)) { best = d; bf = of; }
+        // disc lower bound (squared) of triangle t for point q
+        auto disc_lb2 = [&](const float4 sp, const float4 tn, f3 q) {
+            const float ex = q.x - sp.x, ey = q.y - sp.y, ez = q.z - sp.z;
+            const float e2 = (ex * ex + ey * ey) + ez * ez;
+            const float h = (tn.x * ex + tn.y * ey) + tn.z * ez;
+            const float h2 = h * h;
+            const float gr = fmaxf(sqrtf(fmaxf(e2 * (1.0f - kappa) - h2 - tn.w, 0.0f)) - sp.w, 0.0f);
+            return fmaxf(h2 - kappa * e2 - tn.w, 0.0f) + gr * gr;
+        };
+        auto eval_t = [&](int t) { // the record comes through wave-uniform (scalar) loads: t is the same in every lane
+            const float4 sp = reinterpret_cast<const float4*>(A.sphere)[t];
+            const float4 tn = reinterpret_cast<const float4*>(A.tnorm)[t];
+            if (disc_lb2(sp, tn, p) > fminf(best, vb) * (1.0f + 1e-4f) + 1e-12f) return;
+            const float* q = A.tri + (size_t)t * 9;
+            const f3 a = {q[0], q[1], q[2]}, b = {q[3], q[4], q[5]}, c3 = {q[6], q[7], q[8]};
+            const float d = point_tri_dist2(p, a, b, c3);
+            const int of = A.orig[t];
+            if (d < best || (d == best && of < bf)) { best = d; bf = of; }
+        };
+        // (1) seed: the cluster nearest to the centre of T, all of its triangles, so that every lane holds a bound close to its answer
+        const f3 tc = {0.5f * (tlo[0] + thi[0]), 0.5f * (tlo[1] + thi[1]), 0.5f * (tlo[2] + thi[2])};
+        int cseed = 0;
+        {
+            float smin = INFINITY;
+            for (int c = lane; c < A.nc; c += 64) {
+                const float lb = box_dist2(tc, s_box + 6 * c);
+                if (lb < smin) { smin = lb; cseed = c; }
+            }
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) {
+                const float o = __shfl_xor(smin, m);
+                const int oc = __shfl_xor(cseed, m);
+                if (o < smin || (o == smin && oc < cseed)) { smin = o; cseed = oc; }
+            }
+            cseed = __builtin_amdgcn_readfirstlane(cseed);
+            for (int k = 0; k < CL; ++k) eval_t(cseed * CL + k);
+        }
+        // (2) the other clusters: 64 at a time against T with the wave's largest bound, the survivors by every lane against its own
+        const float capf = wave_max(fminf(best, vb)) * (1.0f + 1e-4f) + 1e-12f;
+        for (int c0 = 0; c0 < A.nc; c0 += 64) {
+            const int cl_ = c0 + lane;
+            unsigned long long cm_ = __ballot(cl_ < A.nc && cl_ != cseed && tile_dist2(s_box + 6 * min(cl_, A.nc - 1)) <= capf);
+            while (cm_) {
+                const int c = c0 + __builtin_ctzll(cm_);
+                cm_ &= cm_ - 1;
+                if (box_dist2(p, s_box + 6 * c) > fminf(best, vb) * (1.0f + 1e-4f) + 1e-12f) continue;
+                for (int k = 0; k < CL; ++k) eval_t(c * CL + k);
             }
         }
+        MPH(2); // closest face
         // inside test on the (y,z) grid
         int cnt = 0;
         {
@@ -355,9 +449,10 @@ __global__ __launch_bounds__(MA_BLOCK) void mesh_query_accel_kernel(const Vanerf
                 }
             }
         }
+        MPH(3); // inside test
         const float dist = sqrtf(best + 1e-6f);
-        sdf[i] = (cnt & 1) ? -dist : dist;
-        if (face) face[i] = bf;
+        if (act) sdf[i] = (cnt & 1) ? -dist : dist;
+        if (face && act) face[i] = bf;
         const int i0 = F[3 * bf], i1 = F[3 * bf + 1], i2 = F[3 * bf + 2];
         const f3 v0 = {V[3 * i0], V[3 * i0 + 1], V[3 * i0 + 2]}, v1 = {V[3 * i1], V[3 * i1 + 1], V[3 * i1 + 2]},
                  v2 = {V[3 * i2], V[3 * i2 + 1], V[3 * i2 + 2]};
@@ -373,8 +468,13 @@ __global__ __launch_bounds__(MA_BLOCK) void mesh_query_accel_kernel(const Vanerf
         const float b1 = dot3(c2, nrm) * inv;
         const float w0 = (1.0f - b1) - b2;
         const float sv = (w0 * vert_vis[i0] + b1 * vert_vis[i1]) + b2 * vert_vis[i2];
-        vis[i] = sv >= 0.1f;
+        if (act) vis[i] = sv >= 0.1f;
+        MPH(4); // visibility + stores
     }
+#ifdef VANERF_MESH_PHASES
+    if ((threadIdx.x & 63) == 0)
+        for (int k = 0; k < 8; ++k) atomicAdd(&g_ma_phase[k], ph[k]);
+#endif
 }
 
 } // namespace
@@ -429,7 +529,7 @@ extern "C" int vanerf_mesh_query_accel(const VanerfMeshAccel* accel, const float
         if (n == 0) return; // an empty batch is valid (and has null data pointers)
         if (!accel || !verts || !faces || !vert_vis || !pts || !sdf || !vis) throw_error("vanerf_mesh_query_accel: null argument");
         const VanerfMeshAccel& A = *accel;
-        if (!A.tri || !A.sphere || !A.orig || !A.cbox || !A.cell_start || !A.cell_tri) throw_error("vanerf_mesh_query_accel: accel has a null pointer");
+        if (!A.tri || !A.sphere || !A.tnorm || !A.orig || !A.cbox || !A.cell_start || !A.cell_tri) throw_error("vanerf_mesh_query_accel: accel has a null pointer");
         if (A.nc <= 0 || A.nc > MA_MAX_CLUSTERS || A.nfp != A.nc * CL || A.nfp < nf) throw_error("vanerf_mesh_query_accel: bad cluster table (nc=%d nfp=%d nf=%d)", A.nc, A.nfp, nf);
         if (A.G <= 0 || !(A.cell_y > 0.0f) || !(A.cell_z > 0.0f)) throw_error("vanerf_mesh_query_accel: bad grid");
         if (nv <= 0 || nf <= 0 || n < 0) throw_error("vanerf_mesh_query_accel: nv=%d nf=%d n=%lld", nv, nf, (long long)n);
@@ -447,3 +547,13 @@ extern "C" int vanerf_mesh_query_accel(const VanerfMeshAccel* accel, const float
         HIP_CHECK(hipGetLastError());
     });
 }
+
+#ifdef VANERF_MESH_PHASES
+extern "C" int vanerf_debug_mesh_phases(unsigned long long* out8, int reset)
+{
+    return guarded([&] {
+        HIP_CHECK(hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_ma_phase), sizeof(unsigned long long) * 8));
+        if (reset) { unsigned long long z[8] = {}; HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_ma_phase), z, sizeof z)); }
+    });
+}
+#endif

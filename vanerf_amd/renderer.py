@@ -202,8 +202,14 @@ class MeshAccel:
         self.tri = tri_s.reshape(nfp, 9).contiguous()
         self.orig = torch.cat([order.to(torch.int32), torch.full((pad,), 0x7FFFFFFF, dtype=torch.int32, device=dev)]).contiguous()
         cen = tri_s.mean(1)
-        rad = (tri_s - cen[:, None]).norm(dim=-1).max(1)[0] * (1.0 + 1e-5) + 1e-9
+        a_t = tri_s.abs().amax((1, 2)) * 1e-6 + 1e-9  # absolute slack of the oriented bounds (fp32 error of centres and normals)
+        rad = (tri_s - cen[:, None]).norm(dim=-1).max(1)[0] * (1.0 + 1e-5) + a_t
         self.sphere = torch.cat([cen, rad[:, None]], 1).contiguous()
+        # oriented bounds: the triangle lies in the plane through its centroid, within `rad` of it
+        nrm = torch.linalg.cross(tri_s[:, 1] - tri_s[:, 0], tri_s[:, 2] - tri_s[:, 0])
+        nlen = nrm.norm(dim=-1, keepdim=True)
+        unit = torch.where(nlen > 1e-20, nrm / nlen.clamp_min(1e-30), torch.zeros_like(nrm))
+        self.tnorm = torch.cat([unit, (1e5 * a_t * a_t)[:, None]], 1).contiguous()
         cl = tri_s.reshape(nfp // self.CL, self.CL * 3, 3)
         self.cbox = torch.cat([cl.min(1)[0], cl.max(1)[0]], 1).contiguous()
         # (y,z) grid: cell index = clamp(floor((c - c0) / cell), 0, G-1) -- the SAME fp32 expression as the kernel, so the
@@ -242,6 +248,7 @@ class MeshAccel:
         c = VanerfMeshAccel()
         c.vsort, c.vbox, c.nvc = _ptr(self.vsort, f32), _ptr(self.vbox, f32), nvp // self.CL
         c.tri, c.sphere, c.orig, c.cbox = _ptr(self.tri, f32), _ptr(self.sphere, f32), _ptr(self.orig, torch.int32), _ptr(self.cbox, f32)
+        c.tnorm = _ptr(self.tnorm, f32)
         c.nfp, c.nc = nfp, nfp // self.CL
         c.cell_start, c.cell_tri = _ptr(self.cell_start, torch.int32), _ptr(self.cell_tri, torch.int32)
         c.G, c.y0, c.z0, c.cell_y, c.cell_z = G, y0, z0, cell_y, cell_z
