@@ -148,6 +148,13 @@ def make_frame(seed=0, tar_h=64, tar_w=64, src_hw=256, orbit_deg=8.0, device="cp
     return to_device(frame, device)
 
 
+def to_tr_batch(frame):
+    """The dict VANeRFLightningModule.decode_batch hands to the renderer (reference src/model.py:213-262), filled from a synthetic frame."""
+    return {"im": frame["img_in"], "cam": frame["cam_in"], "hand_type": frame["hand_type"], "targets": frame["targets"], "sp_data": frame["sp_data"],
+            "src_foreground_mask": frame["src_foreground_mask"],
+            "dr_data": {"tar": None, "cam_tar": frame["cam_tar"], "objcenter": None, "bounds": frame["bounds"], "mask_at_box": None}}
+
+
 def to_device(obj, device):
     if isinstance(obj, torch.Tensor):
         return obj.to(device)
