@@ -96,7 +96,11 @@ typedef struct VanerfWeights VanerfWeights; /* opaque device-resident packed wei
 int vanerf_abi_version(void);
 const char* vanerf_last_error(void);
 
-/* Packs the weight table into MFMA fragment order on the device.  mode: 0 = fp32 (exact, v_mfma_f32_32x32x2_f32). */
+/* Packs the weight table into MFMA fragment order on the device.  mode selects the arithmetic of the 20 dense layers that
+ * vanerf_query_samples runs with these weights:
+ *   0  fp32:   v_mfma_f32_32x32x2_f32 on fp32 weights and activations (summation order is the only difference to the reference)
+ *   1  bf16x3: v_mfma_f32_32x32x16_bf16, fp32 accumulate, W = W_hi + W_lo and X = X_hi + X_lo (bf16 each), three products per term;
+ *              outputs within 3.3e-5 of mode 0 on the 10.9 M-sample benchmark launch, about twice as fast */
 int vanerf_weights_pack(const VanerfWeightTable* w, int mode, VanerfWeights** out);
 int vanerf_weights_free(VanerfWeights* w);
 /* Diagnostics: number of 32-sample groups (since the pack) for which vanerf_query_samples took its all-invalid short path
