@@ -203,6 +203,7 @@ template <int NB, int T> __device__ __forceinline__ RingB<NB> ring_start_b(WRsrc
         constexpr int i = decltype(ic)::value;
         if constexpr (i < S) r.f[i] = wload_b<NB>(rs, sbase_dw + i * NB * 512, vb);
     });
+    __builtin_amdgcn_sched_barrier(0x000F); // keep the ring fill where it is written: ahead of the previous layer's epilogue
     return r;
 }
 
@@ -214,38 +215,65 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b)
 
 struct NoPre { template <class C> __device__ __forceinline__ void operator()(C) const {} };
 
-// pre(integral_constant<int, s>) runs before the operands of bf16 step s are gathered (lazy producers, e.g. the positional encoding)
+// pre(integral_constant<int, s>) runs before the operands of bf16 step s are gathered (lazy producers, e.g. the positional encoding).
+//
+// Software pipeline, written out and pinned.  One wave per SIMD issues in order: a bf16 32x32x16 MFMA costs the wave ~16 issue cycles
+// and then runs 34 cycles beside whatever the wave issues next, so up to ~4 VALU instructions per MFMA are free -- IF they stand
+// between the MFMAs (tools/probe_bf16_valu.hip).  Left to itself the machine scheduler emits the 3*NB MFMAs of a k-step back to
+// back (the wave sits in MFMA issue) and then the operand split of the next step (the matrix pipe idles), and it sinks every ring
+// re-load to just above its use (no prefetch).  An ablation priced that at 5 ms of MFMA time added to 4.4 ms of everything else.
+// So: step s's MFMAs are cut into four chunks, after each chunk comes one pair-split of step s+1's operands (5 VALU), the re-load of
+// the consumed ring slot is issued before the first chunk, and a sched_barrier(0) after every chunk keeps that order.
+// (sched_group_barrier could request the same interleave, but its solver did not finish on this 10 k-instruction block in 15 min.)
 template <int NB, int T, class Op, class Pre = NoPre>
 __device__ __forceinline__ void run_layer_b(f32x16 (&acc)[NB], RingB<NB>& ring, WRsrc rs, unsigned sbase_dw, unsigned vb, Op&& operand,
                                             Pre&& pre = Pre{})
 {
     constexpr int D = RingDepthB<NB>::value, S = (T + 7) / 8;
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    // hi = bf16(x) (round to nearest even), lo = bf16(x - hi) for operand pair i of step s: 5 VALU -- v_cvt_pk, v_lshlrev, v_and, ONE
+    // v_pk_add_f32 for both subtractions, v_cvt_pk.  The empty asm keeps the packed hi opaque: without it the compiler re-converts
+    // each element on its own to feed the subtraction (7 per pair).
+    auto split_pair = [&](auto sc, auto ic, u32x4& bh, u32x4& bl) {
+        constexpr int s = decltype(sc)::value, i = decltype(ic)::value, t0 = 8 * s + 2 * i;
+        float x0 = 0.0f, x1 = 0.0f;
+        if constexpr (t0 < T) x0 = operand(std::integral_constant<int, t0>{});
+        if constexpr (t0 + 1 < T) x1 = operand(std::integral_constant<int, t0 + 1>{});
+        unsigned hpk = pack_bf16(x0, x1);
+        asm("" : "+v"(hpk));
+        bh[i] = hpk;
+        const f32x2 xv = {x0, x1};
+        const f32x2 hv = {__uint_as_float(hpk << 16), __uint_as_float(hpk & 0xffff0000u)};
+        const f32x2 lo = xv - hv;
+        bl[i] = pack_bf16(lo.x, lo.y);
+    };
+    u32x4 bh, bl;
+    pre(std::integral_constant<int, 0>{});
+    static_for<4>([&](auto ic) { split_pair(std::integral_constant<int, 0>{}, ic, bh, bl); });
+    __builtin_amdgcn_sched_barrier(0);
     static_for<S>([&](auto sc) {
         constexpr int s = decltype(sc)::value;
-        pre(sc);
-        float x[8];
-        static_for<8>([&](auto jc) {
-            constexpr int j = decltype(jc)::value, t = 8 * s + j;
-            if constexpr (t < T) x[j] = operand(std::integral_constant<int, t>{});
-            else x[j] = 0.0f;
-        });
-        u32x4 bh, bl;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const unsigned hpk = pack_bf16(x[2 * i], x[2 * i + 1]);
-            bh[i] = hpk;
-            bl[i] = pack_bf16(x[2 * i] - __uint_as_float(hpk << 16), x[2 * i + 1] - __uint_as_float(hpk & 0xffff0000u));
-        }
         const WFragB<NB> a = ring.f[s % D];
         if constexpr (s + D < S) ring.f[s % D] = wload_b<NB>(rs, sbase_dw + (s + D) * NB * 512, vb);
         const bf16x8 xh = __builtin_bit_cast(bf16x8, bh), xl = __builtin_bit_cast(bf16x8, bl);
-#pragma unroll
-        for (int ob = 0; ob < NB; ++ob) {
-            const bf16x8 wh = __builtin_bit_cast(bf16x8, a.hi[ob]), wl = __builtin_bit_cast(bf16x8, a.lo[ob]);
-            acc[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xh, acc[ob], 0, 0, 0);
-            acc[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xl, acc[ob], 0, 0, 0);
-            acc[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, xh, acc[ob], 0, 0, 0);
-        }
+        u32x4 nh = {}, nl = {};
+        // MFMA m of the step (m = 3*ob + product) belongs to chunk m * 4 / (3*NB); products of one block stay in order hh, hl, lh
+        static_for<4>([&](auto cc) {
+            constexpr int c = decltype(cc)::value;
+            static_for<3 * NB>([&](auto mc) {
+                constexpr int m = decltype(mc)::value, ob = m / 3, pr = m % 3;
+                if constexpr (m * 4 / (3 * NB) == c) {
+                    const bf16x8 wh = __builtin_bit_cast(bf16x8, a.hi[ob]), wl = __builtin_bit_cast(bf16x8, a.lo[ob]);
+                    acc[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pr == 2 ? wl : wh, pr == 1 ? xl : xh, acc[ob], 0, 0, 0);
+                }
+            });
+            if constexpr (s + 1 < S) {
+                if constexpr (c == 0) pre(std::integral_constant<int, s + 1>{});
+                split_pair(std::integral_constant<int, s + 1>{}, cc, nh, nl);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        bh = nh; bl = nl;
     });
 }
 
@@ -441,6 +469,14 @@ __global__ __launch_bounds__(BLOCK, MODE == 1 ? VANERF_WAVES_PER_SIMD_B : VANERF
         if (lane == 0) v = atomicAdd(P.queue, 1u);
         return (unsigned)__builtin_amdgcn_readfirstlane((int)v);
     };
+    // split-bf16 kernel (one wave per SIMD, 512 registers): the lane half's 21 key points stay in registers for the whole launch
+    // (63 VGPRs) -- per-group scalar loads of them exposed their latency 21 times per group with no second wave to hide it
+    [[maybe_unused]] float kpx[PE_KPT_PER_HALF], kpy[PE_KPT_PER_HALF], kpz[PE_KPT_PER_HALF];
+    if constexpr (MODE == 1) {
+        const float4* __restrict__ kpl = reinterpret_cast<const float4*>(F.kpt_cam) + (h ? PE_KPT_PER_HALF : 0);
+#pragma unroll
+        for (int i = 0; i < PE_KPT_PER_HALF; ++i) { const float4 k = kpl[i]; kpx[i] = k.x; kpy[i] = k.y; kpz[i] = k.z; }
+    }
     unsigned short_groups = 0;
     unsigned g_next = claim();
     while (g_next < (unsigned)ngroups) {
@@ -561,11 +597,13 @@ __global__ __launch_bounds__(BLOCK, MODE == 1 ? VANERF_WAVES_PER_SIMD_B : VANERF
                     // v_sin_f32 / v_cos_f32 take revolutions, so the arguments are dz/2, dz, 2dz exactly (|error| < 1.6e-7 absolute over
                     // the hand's extent, tools/probe_trig.hip)
                     auto pe_features = [&](int i, float (&feat)[PE_FEATS]) {
-                        // key points through the scalar cache (wave-uniform addresses), selected per lane half.  No LDS in this
-                        // kernel: with two waves per SIMD an LDS return into a register that a just-issued (but queued) bf16 MFMA
-                        // still reads as its B operand corrupted columns 16..31 (tools/diag_mode1b.py).
-                        const float4 k0 = kpg[i], k1 = kpg[PE_KPT_PER_HALF + i];
-                        const float kx = h ? k1.x : k0.x, ky = h ? k1.y : k0.y, kz = h ? k1.z : k0.z;
+                        // fp32 kernel: key points through the scalar cache (wave-uniform addresses), selected per lane half
+                        float kx, ky, kz;
+                        if constexpr (MODE == 1) { kx = kpx[i]; ky = kpy[i]; kz = kpz[i]; }
+                        else {
+                            const float4 k0 = kpg[i], k1 = kpg[PE_KPT_PER_HALF + i];
+                            kx = h ? k1.x : k0.x; ky = h ? k1.y : k0.y; kz = h ? k1.z : k0.z;
+                        }
                         const float ddx = cx - kx, ddy = cy - ky, ddz = cz - kz;
                         const float d2 = (ddx * ddx + ddy * ddy) + ddz * ddz;
                         const float wk = __expf(-d2 * F.pe_inv_2sigma2);
