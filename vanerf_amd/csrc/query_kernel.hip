@@ -337,6 +337,18 @@ template <int NB> __device__ __forceinline__ void softplus(f32x16 (&a)[NB])
         for (int r = 0; r < 16; ++r) a[ob][r] = softplus100(a[ob][r]);
 }
 
+// Activation at the point of use.  An activation output is consumed exactly once, as a B operand of the next layer.  The fp32 kernel
+// applies the activation to a whole accumulator block right after its layer (VALU time adds to fp32-MFMA time wherever it stands); the
+// split-bf16 kernel applies it when the operand is gathered, inside the software pipeline of run_layer_b, where VALU work runs beside
+// the MFMAs of the previous k-step.  Same function, same values, same results.
+enum Act { ACT_RELU = 1, ACT_SOFTPLUS = 2 };
+template <int MODE, int ACT> __device__ __forceinline__ float lazy_act(float v)
+{
+    if constexpr (MODE == 0) return v; // already applied in bulk
+    else if constexpr (ACT == ACT_RELU) return relu_f(v);
+    else return softplus100(v);
+}
+
 // ---------------------------------------------------------------------------------------------
 // grid_sample(bilinear, border, align_corners=True) (src/utils.py:136-151)
 // ---------------------------------------------------------------------------------------------
@@ -423,10 +435,10 @@ __device__ __forceinline__ void geo_scale(WRsrc W, int lane, typename RingSel<MO
     run_layer_m<MODE, 1, TIN, l_at_a>(at, ring_at, W, lane, input);
     auto r_gate = ring_start_m<MODE, 1, 6, l_at_a + 1>(W, lane);
     auto r_mid = ring_start_m<MODE, NBO, TIN, l_at_a + 2>(W, lane);
-    relu<1>(at);
+    if constexpr (MODE == 0) relu<1>(at);
     f32x16 gate[1];
     zero<1>(gate);
-    run_layer_m<MODE, 1, 6, l_at_a + 1>(gate, r_gate, W, lane, [&](auto tc) -> float { return at[0][decltype(tc)::value]; });
+    run_layer_m<MODE, 1, 6, l_at_a + 1>(gate, r_gate, W, lane, [&](auto tc) -> float { return lazy_act<MODE, ACT_RELU>(at[0][decltype(tc)::value]); });
     // gates live in rows 0..2 = registers 0..2 of the h = 0 lanes
     const float a0 = __shfl(sigmoid_f(gate[0][0]), lane & 31);
     const float a1 = __shfl(sigmoid_f(gate[0][1]), lane & 31);
@@ -437,10 +449,10 @@ __device__ __forceinline__ void geo_scale(WRsrc W, int lane, typename RingSel<MO
     zero<NBO>(mid);
     run_layer_m<MODE, NBO, TIN, l_at_a + 2>(mid, r_mid, W, lane, input);
     auto r_out = ring_start_m<MODE, NBO, TOUT, l_at_a + 3>(W, lane);
-    relu<NBO>(mid);
+    if constexpr (MODE == 0) relu<NBO>(mid);
     zero<NBO>(outacc);
     run_layer_m<MODE, NBO, TOUT, l_at_a + 3>(outacc, r_out, W, lane,
-                         [&](auto tc) -> float { constexpr int t = decltype(tc)::value; return mid[t / 16][t % 16]; });
+                         [&](auto tc) -> float { constexpr int t = decltype(tc)::value; return lazy_act<MODE, ACT_RELU>(mid[t / 16][t % 16]); });
 }
 
 template <int MODE>
@@ -529,6 +541,11 @@ __global__ __launch_bounds__(BLOCK, MODE == 1 ? VANERF_WAVES_PER_SIMD_B : VANERF
         auto chain = [&](auto& src, auto tc, auto nsteps) -> float {
             constexpr int t = decltype(tc)::value;
             if constexpr (t < decltype(nsteps)::value) return src[t / 16][t % 16];
+            else return one_h0;
+        };
+        auto chain_sp = [&](auto& src, auto tc, auto nsteps) -> float { // the same through Softplus (lazy_act)
+            constexpr int t = decltype(tc)::value;
+            if constexpr (t < decltype(nsteps)::value) return lazy_act<MODE, ACT_SOFTPLUS>(src[t / 16][t % 16]);
             else return one_h0;
         };
         float row[32]; // h = 0: nearest vertex [img3|tex8|gf18], h = 1: twin vertex
@@ -662,23 +679,23 @@ __global__ __launch_bounds__(BLOCK, MODE == 1 ? VANERF_WAVES_PER_SIMD_B : VANERF
                 }
                 STAMP(5); // mlp0 (PE + geo64)
                 auto r1 = ring_start_m<MODE, 4, 65, L_MLP1>(W, lane);
-                softplus<4>(a0);
+                if constexpr (MODE == 0) softplus<4>(a0);
                 f32x16 a1[4];
                 zero<4>(a1);
-                run_layer_m<MODE, 4, 65, L_MLP1>(a1, r1, W, lane, [&](auto tc) -> float { return chain(a0, tc, std::integral_constant<int, 64>{}); });
+                run_layer_m<MODE, 4, 65, L_MLP1>(a1, r1, W, lane, [&](auto tc) -> float { return chain_sp(a0, tc, std::integral_constant<int, 64>{}); });
                 auto r2 = ring_start_m<MODE, 4, 69, L_MLP2>(W, lane);
-                softplus<4>(a1);
+                if constexpr (MODE == 0) softplus<4>(a1);
                 zero<4>(a0);
                 run_layer_m<MODE, 4, 69, L_MLP2>(a0, r2, W, lane, [&](auto tc) -> float {
                     constexpr int t = decltype(tc)::value;
-                    if constexpr (t < 64) return a1[t / 16][t % 16];
+                    if constexpr (t < 64) return lazy_act<MODE, ACT_SOFTPLUS>(a1[t / 16][t % 16]);
                     else if constexpr (t < 68) return g8[0][t - 64];
                     else return one_h0;
                 });
                 auto r3 = ring_start_m<MODE, 2, 61, L_MLP3>(W, lane);
-                softplus<4>(a0);
+                if constexpr (MODE == 0) softplus<4>(a0);
                 zero<2>(xv);
-                run_layer_m<MODE, 2, 61, L_MLP3>(xv, r3, W, lane, [&](auto tc) -> float { return chain(a0, tc, std::integral_constant<int, 60>{}); });
+                run_layer_m<MODE, 2, 61, L_MLP3>(xv, r3, W, lane, [&](auto tc) -> float { return chain_sp(a0, tc, std::integral_constant<int, 60>{}); });
             }
             STAMP(6); // softplus x3 + mlp1..3
             tex_gathers();
@@ -699,13 +716,13 @@ __global__ __launch_bounds__(BLOCK, MODE == 1 ? VANERF_WAVES_PER_SIMD_B : VANERF
                 zero<2>(m0);
                 run_layer_m<MODE, 2, 65, L_HEAD0>(m0, rh0, W, lane, [&](auto tc) -> float { return chain(pool, tc, std::integral_constant<int, 64>{}); });
                 auto rh1 = ring_start_m<MODE, 2, 33, L_HEAD1>(W, lane);
-                softplus<2>(m0);
+                if constexpr (MODE == 0) softplus<2>(m0);
                 zero<2>(m1);
-                run_layer_m<MODE, 2, 33, L_HEAD1>(m1, rh1, W, lane, [&](auto tc) -> float { return chain(m0, tc, std::integral_constant<int, 32>{}); });
+                run_layer_m<MODE, 2, 33, L_HEAD1>(m1, rh1, W, lane, [&](auto tc) -> float { return chain_sp(m0, tc, std::integral_constant<int, 32>{}); });
                 auto rh2 = ring_start_m<MODE, 1, 33, L_HEAD2>(W, lane);
-                softplus<2>(m1);
+                if constexpr (MODE == 0) softplus<2>(m1);
                 zero<1>(head);
-                run_layer_m<MODE, 1, 33, L_HEAD2>(head, rh2, W, lane, [&](auto tc) -> float { return chain(m1, tc, std::integral_constant<int, 32>{}); });
+                run_layer_m<MODE, 1, 33, L_HEAD2>(head, rh2, W, lane, [&](auto tc) -> float { return chain_sp(m1, tc, std::integral_constant<int, 32>{}); });
             }
         } else {
             tex_gathers();
@@ -738,12 +755,12 @@ __global__ __launch_bounds__(BLOCK, MODE == 1 ? VANERF_WAVES_PER_SIMD_B : VANERF
                 else if constexpr (t == 47) return t0;
                 else return t1;
             };
-            auto from_ta = [&](auto& ta_) { return [&](auto tc) -> float { constexpr int t = decltype(tc)::value; return ta_[t / 16][t % 16]; }; };
+            auto from_ta = [&](auto& ta_) { return [&](auto tc) -> float { constexpr int t = decltype(tc)::value; return lazy_act<MODE, ACT_RELU>(ta_[t / 16][t % 16]); }; };
             f32x16 ta[3];
             zero<3>(ta);
             run_layer_m<MODE, 3, 49, L_TEX_AT_A>(ta, r_ta, W, lane, tex_in);
             auto r_tg = ring_start_m<MODE, 1, 48, L_TEX_AT_B>(W, lane);
-            relu<3>(ta);
+            if constexpr (MODE == 0) relu<3>(ta);
             f32x16 tg[1];
             zero<1>(tg);
             run_layer_m<MODE, 1, 48, L_TEX_AT_B>(tg, r_tg, W, lane, from_ta(ta));
@@ -766,7 +783,7 @@ __global__ __launch_bounds__(BLOCK, MODE == 1 ? VANERF_WAVES_PER_SIMD_B : VANERF
             zero<3>(ta);
             run_layer_m<MODE, 3, 49, L_TEX_A>(ta, r_tb, W, lane, tex_in);
             auto r_rgb = ring_start_m<MODE, 1, 48, L_TEX_B>(W, lane);
-            relu<3>(ta);
+            if constexpr (MODE == 0) relu<3>(ta);
             zero<1>(rgb);
             run_layer_m<MODE, 1, 48, L_TEX_B>(rgb, r_rgb, W, lane, from_ta(ta));
         }
