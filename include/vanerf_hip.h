@@ -143,20 +143,23 @@ int vanerf_mesh_query(const float* verts, int nv, const int32_t* faces, int nf, 
 
 /* Acceleration structure for vanerf_mesh_query_accel (built per source frame on the device by the caller, see
  * vanerf_amd/renderer.py:MeshAccel).  Results are bit-identical to vanerf_mesh_query.                                   */
+/* Triangles / vertices per cluster the library was built with (the caller builds its tables with this value). */
+int vanerf_mesh_cluster_size(void);
+
 typedef struct {
-    const float* tri;          /* [nfp][9]  triangle corners, Morton-sorted, padded to a multiple of 16 with far-away triangles */
+    const float* tri;          /* [nfp][9]  triangle corners, Morton-sorted, padded to a multiple of the cluster size with far-away triangles */
     const float* sphere;       /* [nfp][4]  bounding sphere of each triangle (centroid, radius) */
     const float* tnorm;        /* [nfp][4]  unit normal of each triangle (0 for a degenerate one), w = rounding allowance 1e5 a^2: with `sphere` the triangle lies in the
                                 *           disc {centroid + u : u normal to tnorm, |u| <= radius} -- the lower bound the search prunes with */
     const int32_t* orig;       /* [nfp]     original face index (INT32_MAX for padding) */
-    const float* cbox;         /* [nc][6]   AABB of each cluster of 16 triangles (lo xyz, hi xyz) */
+    const float* cbox;         /* [nc][6]   AABB of each cluster of vanerf_mesh_cluster_size() consecutive triangles (lo xyz, hi xyz) */
     int nfp, nc;
     const int32_t* cell_start; /* [G*G + 1] CSR offsets of the (y,z) grid used by the inside test */
     const int32_t* cell_tri;   /* original face ids per cell */
     int G;
     float y0, z0, cell_y, cell_z;
-    const float* vsort;        /* [nvc*16][4] Morton-sorted vertices (xyz, original index as int bits), padded with far points */
-    const float* vbox;         /* [nvc][6]    AABB of each cluster of 16 vertices */
+    const float* vsort;        /* [nvc*CL][4] Morton-sorted vertices (xyz, original index as int bits), padded with far points */
+    const float* vbox;         /* [nvc][6]    AABB of each cluster of CL vertices */
     int nvc;
 } VanerfMeshAccel;
 

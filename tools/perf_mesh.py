@@ -37,4 +37,4 @@ if "--phases" in sys.argv:  # needs VANERF_HIPCC_FLAGS=-DVANERF_MESH_PHASES
     for name, v in zip(["point load", "1-NN vertex", "closest face", "inside test", "visibility + stores"], buf):
         print(f"  {name:20s} {100.0 * v / tot:5.1f} %  {v / (pts.shape[0] / 64):9.0f} cycles per 64 points")
     nw = pts.shape[0] / 64
-    print(f"  per wave of 64 points: {buf[5] / nw:.1f} rounds of 4 clusters, {buf[6] / nw:.1f} candidate triangles, {buf[7] / nw:.1f} exact evaluations")
+    print(f"  per wave of 64 points: {buf[5] / nw:.1f} clusters pass the wave-level test, {buf[6] / nw:.1f} are opened by some lane (16 bound tests each), {buf[7] / nw:.1f} exact evaluations")

@@ -53,6 +53,7 @@ class VanerfMeshAccel(Structure):
 _SIGS = {
     "vanerf_abi_version": (c_int, []),
     "vanerf_last_error": (c_char_p, []),
+    "vanerf_mesh_cluster_size": (c_int, []),
     "vanerf_weights_pack": (c_int, [POINTER(VanerfWeightTable), c_int, POINTER(c_void_p)]),
     "vanerf_weights_free": (c_int, [c_void_p]),
     "vanerf_weights_short_groups": (c_int, [c_void_p, POINTER(c_uint64)]),

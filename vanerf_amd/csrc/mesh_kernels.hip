@@ -228,7 +228,11 @@ __global__ __launch_bounds__(256) void knn1_kernel(const float4* __restrict__ ve
 //   * inside test: a G x G grid over the mesh's (y,z) extent lists the triangles whose (y,z) bounding box touches each
 //     cell; the +x ray of a point can only cross triangles of its own cell.
 // The structure is built per source frame by vanerf_amd/renderer.py:MeshAccel (torch on the device).
-constexpr int CL = 16; // triangles per cluster
+#ifndef VANERF_MA_CL
+#define VANERF_MA_CL 4
+#endif
+constexpr int CL = VANERF_MA_CL; // triangles (and vertices) per cluster.  Measured on the benchmark view: 16 -> 6.35 ms, 8 -> 4.80, 4 -> 4.37
+                                 // (box tests are cheap since they are done per wave first; small clusters mean fewer per-triangle tests)
 #ifndef VANERF_MA_BLOCK
 #define VANERF_MA_BLOCK 512
 #endif
@@ -389,6 +393,9 @@ __global__ __launch_bounds__(MA_BLOCK) void mesh_query_accel_kernel(const Vanerf
             const float* q = A.tri + (size_t)t * 9;
             const f3 a = {q[0], q[1], q[2]}, b = {q[3], q[4], q[5]}, c3 = {q[6], q[7], q[8]};
             const float d = point_tri_dist2(p, a, b, c3);
+#ifdef VANERF_MESH_PHASES
+            if (__builtin_ctzll(__ballot(1)) == lane) ph[7] += 1; // exact evaluations (some lane)
+#endif
             const int of = A.orig[t];
             if (d < best || (d == best && of < bf)) { best = d; bf = of; }
         };
@@ -418,7 +425,13 @@ __global__ __launch_bounds__(MA_BLOCK) void mesh_query_accel_kernel(const Vanerf
             while (cm_) {
                 const int c = c0 + __builtin_ctzll(cm_);
                 cm_ &= cm_ - 1;
+#ifdef VANERF_MESH_PHASES
+                if (lane == 0) ph[5] += 1; // clusters surviving the wave-level test
+#endif
                 if (box_dist2(p, s_box + 6 * c) > fminf(best, vb) * (1.0f + 1e-4f) + 1e-12f) continue;
+#ifdef VANERF_MESH_PHASES
+                if (__builtin_ctzll(__ballot(1)) == lane) ph[6] += 1; // ... whose triangles some lane looks at
+#endif
                 for (int k = 0; k < CL; ++k) eval_t(c * CL + k);
             }
         }
@@ -557,3 +570,5 @@ extern "C" int vanerf_debug_mesh_phases(unsigned long long* out8, int reset)
     });
 }
 #endif
+
+extern "C" int vanerf_mesh_cluster_size(void) { return CL; }

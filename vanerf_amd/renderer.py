@@ -183,7 +183,7 @@ def _part1by2(x):
 class MeshAccel:
     """Per-frame acceleration structure of vanerf_mesh_query_accel, built with torch ops on the device:
     Morton-sorted triangle clusters (closest-face search) and a (y,z) cell grid (inside test)."""
-    CL = 16
+    CL = lib.vanerf_mesh_cluster_size()  # triangles / vertices per cluster the library was built with
 
     def __init__(self, verts3, faces_i32, grid=64):
         dev = verts3.device
