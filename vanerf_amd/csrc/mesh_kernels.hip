@@ -4,6 +4,8 @@
 //   knn_points (K=1)    src/networks.py:28
 // The arithmetic is the operation-for-operation twin of oracle/mesh_oracle.c (third-party semantics, parity
 // unpinned against the reference; bit-exact against the oracle).  Built with -ffp-contract=off.
+// (A branch-free point_tri_dist2 with one shared division was measured: bit-exact, but 7 % slower -- the lanes of a wave mostly
+// agree on the Voronoi region, so the branches are cheap.)
 #include "common.h"
 
 using namespace vanerf;
@@ -549,7 +551,9 @@ extern "C" int vanerf_mesh_query_accel(const VanerfMeshAccel* accel, const float
         if (!A.vsort || !A.vbox || A.nvc <= 0 || A.nvc > MA_MAX_VCLUSTERS || A.nvc * CL < nv)
             throw_error("vanerf_mesh_query_accel: bad vertex cluster table (nvc=%d nv=%d)", A.nvc, nv);
         const size_t lds = sizeof(float) * ((size_t)A.nvc * CL * 4 + (size_t)A.nvc * 6 + (size_t)A.nc * 6);
-        if (lds > 64 * 1024) throw_error("vanerf_mesh_query_accel: mesh too large for the LDS-resident tables (%zu bytes)", lds);
+        if (lds > 150 * 1024) throw_error("vanerf_mesh_query_accel: mesh too large for the LDS-resident tables (%zu bytes)", lds);
+        if (lds > 64 * 1024) // above the default dynamic-LDS limit (gfx950 has 160 KB per CU)
+            HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(mesh_query_accel_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         if (n == 0) return;
         if (grid_nx != 0 && (grid_nx < 0 || grid_ny <= 0 || grid_s <= 0 || (long long)grid_nx * grid_ny * grid_s != n))
             throw_error("vanerf_mesh_query_accel: ray-grid hint %d x %d x %d does not match n = %lld", grid_nx, grid_ny, grid_s, (long long)n);
