@@ -5,6 +5,9 @@ module raises.  Build it with `python -m vanerf_amd.build` (or `__graft_entry__.
 """
 import ctypes
 import os
+
+import torch  # noqa: F401  -- FIRST: torch ships its own libamdhip64; if libvanerf_hip.so (linked against /opt/rocm's) is loaded before
+#                          torch, two HIP runtimes live in the process and the second reports "no ROCm-capable device"
 from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int64, c_uint, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
