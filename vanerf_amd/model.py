@@ -9,8 +9,9 @@ What runs where
   * n_views == 1 and batch == 1, as in both shipped configs (the non-spconv reference path is structurally single-view:
     src/networks.py:86,94; render_pifu_nerf hard-codes n_views = 1, src/model.py:1044).
 
-Not differentiable: the fused forward has no backward yet (SURVEY.md section 8 row f-4 "next"); `forward()` therefore serves
-validation / inference-time use, and raises if called with autograd enabled on parameters that require grad.
+Training: `forward()` in train mode under autograd returns the HIP values with the gradients of `vanerf_amd.torch_graph` -- the same
+networks re-evaluated with torch ops at the samples of the HIP pass ("fused HIP forward + PyTorch autograd backward", SURVEY.md
+section 8 row f-4, first stage; a fused HIP backward is not built).  Under no_grad / eval nothing of that runs.
 """
 import copy
 import math
@@ -323,8 +324,11 @@ class VANeRF(nn.Module):
         Rn = out_w * out_h
         jitter = None if uniform else torch.rand(Rn, Sc, device=dev)          # th.rand_like(z), src/model.py:1229
         u = None if uniform else torch.rand(Rn, Sf, device=dev)                # th.rand(...), src/model.py:1443
+        want_graph = bool(config.get("_autograd", False))  # forward() under autograd: keep what vanerf_amd.torch_graph needs
         o = R.render_pass(net.packed_weights(), fd, cam_t, config["bounds"], x0, y0, step, nx, ny, Sc, Sf, fine=fine, jitter=jitter, u=u,
-                          noise_std=float(noise_std), pixels=pixels)
+                          noise_std=float(noise_std), pixels=pixels, debug=want_graph)
+        if want_graph:
+            net._last_pass = (o, fd, cam_in)
         out = {"tex_fg": o["color"].view(1, out_h, out_w, 3).permute(0, 3, 1, 2), "depth": o["depth"].view(1, out_h, out_w),
                "alpha": o["alpha"].view(1, out_h, out_w)}
         if fine:
@@ -385,21 +389,61 @@ class VANeRF(nn.Module):
         ret["vert_vis"] = out["vert_vis"]
         return ret
 
+    def attach_autograd(self, out, img_in, feat_geo, feat_tex, targets, sp_data, fg_mask):
+        """Replaces the differentiable entries of `out` (a batch_render_pifu_nerf result computed with _autograd=True) by tensors that
+        carry the HIP values and the gradients of vanerf_amd.torch_graph evaluated at the same samples (same points, same importance
+        samples, same mesh queries, same noise draws)."""
+        from . import torch_graph as G
+        o, fd, cam_in = self._last_pass
+        self._last_pass = (o, fd, cam_in) if getattr(self, "_keep_last_pass", False) else None  # tests inspect the pass
+        P = dict(self.named_parameters())
+        frame = {"cam": cam_in, "img": img_in, "feat_geo": feat_geo, "feat_tex": feat_tex, "fg_mask": fg_mask.reshape(1, 1, *fg_mask.shape[-2:]),
+                 "verts": targets["vert_world"][0], "vert_vis": fd.vert_vis, "kpt3d": sp_data["kpt3d"], "extrin": sp_data["extrin"]}
+        frame["table29"] = G.texture_vertex_table(P, G.project_vertices(frame["verts"], cam_in), feat_tex, img_in)
+        Rn = o["z"].shape[0]
+        shape = out["depth"].shape  # (1, h, w)
+
+        def evaluate(c):
+            return G.networks_at(P, frame, c["pts"], c["q_sdf"].reshape(-1), c["q_vis"], c["knn"].long(), c["noise"], self.kwargs["sp_args"]).view(Rn, -1, 5)
+
+        c = o["coarse"]
+        rgba_c = evaluate(c)
+        col, dep, acc, _ = G.composite(P, rgba_c, o["z"], c["q_sdf"])
+        graph = {"tex_fg": col.view(1, *shape[1:], 3).permute(0, 3, 1, 2), "depth": dep.view(shape), "alpha": acc.view(shape)}
+        if "fine" in o:
+            f = o["fine"]
+            rgba_f, msdf = evaluate(f), f["q_sdf"]
+            if o.get("fine_src") is not None:  # the pass re-used the coarse evaluations: merge [coarse | new] by the origin map
+                src = o["fine_src"].long()
+                take = torch.where(src >= 0, src, rgba_c.shape[1] + (-src - 1))
+                rgba_f = torch.gather(torch.cat([rgba_c, rgba_f], 1), 1, take[..., None].expand(-1, -1, 5))
+                msdf = torch.gather(torch.cat([c["q_sdf"], f["q_sdf"]], 1), 1, take)
+            col, dep, acc, sdf = G.composite(P, rgba_f, o["z_fine"], msdf)
+            graph.update({"tex_fg_fine": col.view(1, *shape[1:], 3).permute(0, 3, 1, 2), "depth_fine": dep.view(shape), "alpha_fine": acc.view(shape),
+                          "sdf": sdf.view(shape)})
+        for k, g in graph.items():
+            out[k] = G.straight_through(out[k], g)
+        return out
+
     def forward(self, im, cam, hand_type, targets, data, bbox, n_views=1, sp_data={}, dr_data=None, **kwargs):
         """src/model.py:959-1024 (losses are the caller's: compute_error / VGG are outside the hot path).  Returns
         dict(loss=None, err_dict={}, out={'nerf': out_nerf}) with the reference's out_nerf keys."""
         assert len(im.shape) == 4 and len(cam["KRT"].shape) == 3
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()) and self.training:
-            raise NotImplementedError("the fused HIP forward has no backward yet (SURVEY.md section 8, row f-4); call under torch.no_grad()")
+        # Training under autograd ("fused HIP forward + PyTorch autograd backward", SURVEY.md section 8 row f-4, first stage): the values
+        # come from the HIP pass, the gradients from vanerf_amd.torch_graph evaluated at the same samples (attach_autograd below).
+        autograd = torch.is_grad_enabled() and self.training and any(p.requires_grad for p in self.parameters())
         dr_kwargs = self.kwargs.get("dr_kwargs", {})
         feat_geo = self.attach_geo_feat(im, return_val=True)
         feat_tex = self.attach_tex_feat(im, return_val=True)
         n_batch = im.shape[0] // n_views
         stride = 0 if self.dr_level == 1 else torch.randint(high=(2 ** (self.dr_level - 1) - 1), size=(n_batch, 2))
-        out_nerf = self.batch_render_pifu_nerf(self, dr_data["img"], dr_data["cam"], hand_type, targets, n_views, dr_data["cam_tar"], self.dr_level,
-                                               stride, dr_data["tar"], feat_geo, feat_tex, None, sp_data, dr_data.get("objcenter", None),
-                                               msk=dr_data["msk"], src_foreground_mask=kwargs["src_foreground_mask"], bounds=kwargs["bounds"],
-                                               **dr_kwargs)
+        with torch.no_grad():
+            out_nerf = self.batch_render_pifu_nerf(self, dr_data["img"], dr_data["cam"], hand_type, targets, n_views, dr_data["cam_tar"], self.dr_level,
+                                                   stride, dr_data["tar"], [f.detach() for f in feat_geo], feat_tex.detach(), None, sp_data,
+                                                   dr_data.get("objcenter", None), msk=dr_data["msk"], src_foreground_mask=kwargs["src_foreground_mask"],
+                                                   bounds=kwargs["bounds"], _autograd=autograd, **dr_kwargs)
+        if autograd:
+            self.attach_autograd(out_nerf, dr_data["img"], feat_geo, feat_tex, targets, sp_data, kwargs["src_foreground_mask"])
         if self.disable_bg:
             out_nerf["tex_bg"] = 0.0
         out_nerf["tex"] = out_nerf["tex_cal"] = out_nerf["tex_fg"]

@@ -512,7 +512,7 @@ def render_pass(weights, frame, cam_tar, bounds, x0, y0, step, nx, ny, sample_pe
         if kernel_events is not None:
             e1.record()
             kernel_events.append((e0, e1, pts.shape[0]))
-        return dict(pts=pts, q_sdf=q_sdf.view(R, -1), q_vis=q_vis, rgba=rgba.view(R, -1, 5))
+        return dict(pts=pts, q_sdf=q_sdf.view(R, -1), q_vis=q_vis, knn=knn, noise=noise, rgba=rgba.view(R, -1, 5))
 
     c = evaluate(rays["z"])
     c["color"], c["depth"], c["alpha"], c["contrib"], c["sdf"] = composite(c["rgba"], rays["z"], c["q_sdf"], weights.beta)
@@ -532,4 +532,5 @@ def render_pass(weights, frame, cam_tar, bounds, x0, y0, step, nx, ny, sample_pe
         out.update({"color_fine": f["color"], "depth_fine": f["depth"], "alpha_fine": f["alpha"], "sdf": f["sdf"], "z_fine": z_fine})
         if debug:
             out["fine"] = f
+            out["fine_src"] = src if reuse_coarse else None
     return out

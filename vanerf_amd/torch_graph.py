@@ -1,0 +1,190 @@
+"""Differentiable PyTorch statement of the per-sample networks and the compositing, used ONLY to build the autograd graph of a
+training step (first stage: "fused HIP forward + PyTorch autograd backward", BASELINE config 5).
+
+The values of a training step come from the HIP path (vanerf_amd.renderer.render_pass); this module re-evaluates the same networks at
+the SAME sample points -- the points, importance samples, mesh queries (signed distance, visibility, nearest vertex) and noise draws
+are taken from the HIP pass, none of them carries gradient in the reference either (importance_sample runs under no_grad,
+src/model.py:1432; kaolin / pytorch3d inputs are constants) -- with torch ops on the device, so that gradients reach the module's
+parameters and the encoder feature maps.  `straight_through` then returns HIP values with this graph's gradients.
+
+It is not a fallback: nothing here runs unless autograd is recording, and it cannot produce a frame on its own (it has no ray
+generation, no mesh query, no sampling).  Reference anchors: VANeRF.query / query_color src/model.py:748-957, eval_func 1140-1160,
+sdf_activation + rgba2out 879-882, 1464-1494, GeoVisFusion / TexVisFusion src/networks.py:27-106, 219-293, MLPUNetFusion
+src/utils.py:609-880, SpatialEncoder src/spatial.py:20-117.  n_views == 1, batch 1 (as everywhere in this package)."""
+import math
+
+import torch
+import torch.nn.functional as F
+
+NUM_V = 779  # vertices per hand: the "other hand" twin of vertex i is (i + 779) mod 1558 (src/networks.py:30-32)
+
+
+def sample_map(feat, xy):
+    """feat_sample (src/utils.py:136-151): (1,C,H,W) map at (N,2) coordinates in [-1,1] -> (N,C); bilinear, border, align_corners."""
+    out = F.grid_sample(feat, xy.view(1, -1, 1, 2), mode="bilinear", padding_mode="border", align_corners=True)
+    return out.view(feat.shape[1], -1).t()
+
+
+def _linear_wn(P, prefix, x):
+    """Linear of MLPUNetFusion (src/utils.py:670-685): weight-normed, W = g v / ||v||_row, except the last layer of each stack."""
+    if prefix + ".weight_v" in P:
+        v, g = P[prefix + ".weight_v"], P[prefix + ".weight_g"]
+        return F.linear(x, v * (g / v.norm(2, dim=1, keepdim=True)), P[prefix + ".bias"])
+    return F.linear(x, P[prefix + ".weight"], P[prefix + ".bias"])
+
+
+def _conv1(P, key, x):
+    return F.linear(x, P[key][:, :, 0])  # bias-free Conv1d(k = 1) on (N,C)
+
+
+def _softplus(x):
+    return F.softplus(x, beta=100, threshold=20)  # src/utils.py:656
+
+
+def project(pts, cam):
+    """src/model.py:780-788: world points (N,3) -> xy in [-1,1] (N,2), z in [-1,1] (N,1) of the source view."""
+    vh = pts @ cam["KRT"][0, :3, :3].t() + cam["KRT"][0, :3, 3]
+    z = vh[:, 2:3]
+    xy = vh[:, :2] / z
+    xy = torch.stack([2.0 * (xy[:, 0] / (cam["width"] - 1.0)) - 1.0, 2.0 * (xy[:, 1] / (cam["height"] - 1.0)) - 1.0], -1)
+    return xy, 2.0 * (z - cam["znear"]) / (cam["zfar"] - cam["znear"]) - 1.0
+
+
+def project_vertices(vert, cam):
+    """src/model.py:845-853 (z + 1e-8 in the divide)."""
+    vh = vert @ cam["KRT"][0, :3, :3].t() + cam["KRT"][0, :3, 3]
+    xy = vh[:, :2] / (vh[:, 2:3] + 1e-8)
+    return torch.stack([2.0 * (xy[:, 0] / (cam["width"] - 1.0)) - 1.0, 2.0 * (xy[:, 1] / (cam["height"] - 1.0)) - 1.0], -1)
+
+
+def positional_encoding(pts, kpt3d, extrin, levels=3, scale=1.0, sigma=0.1):
+    """SpatialEncoder 'rel_z_decay' (src/spatial.py:59-84, 109-117, 20-43): (N,3) -> (N, (1 + 2 levels) K), blocks [dz | sin.. | cos..] x w."""
+    Rm, t = extrin[0, :3, :3], extrin[0, :3, 3]
+    c = pts @ Rm.t() + t
+    k = kpt3d[0] @ Rm.t() + t
+    d = c[:, None] - k[None]                                          # (N,K,3)
+    w = torch.exp(-(d ** 2).sum(-1) / (2.0 * sigma ** 2))             # (N,K)
+    x = scale * d[..., 2]                                             # (N,K)
+    freq = torch.tensor([math.pi * 2 ** l for l in range(levels)], dtype=torch.float32, device=pts.device)
+    y = x[:, None, :] * freq[None, :, None]                           # (N,L,K)
+    blocks = torch.cat([x[:, None], torch.stack((torch.sin(y), torch.cos(y)), 2).reshape(x.shape[0], -1, x.shape[1])], 1)  # [x | sin l0 | cos l0 | sin l1 | ..]
+    return (blocks * w[:, None]).reshape(pts.shape[0], -1)
+
+
+def _nearest_rows(table, vis, idx):
+    """KNN_vis (src/networks.py:27-33) with the nearest-vertex index given: rows of the nearest vertex and of its twin, x visibility."""
+    twin = (idx + NUM_V) % (2 * NUM_V)
+    return table[idx] * vis[idx, None], table[twin] * vis[twin, None], vis[idx, None], vis[twin, None]
+
+
+def geo_fusion(P, geo_maps, pix, vert_xy, idx, vert_vis, q_vis, q_sdf, pre="geo_vis_fusion."):
+    """GeoVisFusion.forward (src/networks.py:75-106): two scales, gates then a gated 2-layer MLP.  -> [(N,64), (N,8)]."""
+    out = []
+    for i, (at, ated) in enumerate((("fconv_at", "fconv_ated"), ("fconv_at1", "fconv_ated1"))):
+        nn_f, tw_f, vis_nn, vis_tw = _nearest_rows(sample_map(geo_maps[i], vert_xy), vert_vis, idx)
+        tail = [q_sdf, q_vis, vis_nn, vis_tw]
+        a = torch.sigmoid(_conv1(P, pre + at + ".2.weight", torch.relu(_conv1(P, pre + at + ".0.weight", torch.cat([pix[i], nn_f, tw_f] + tail, 1)))))
+        g = torch.cat([pix[i] * a[:, 0:1], nn_f * a[:, 1:2], tw_f * a[:, 2:3]] + tail, 1)
+        out.append(_conv1(P, pre + ated + ".2.weight", torch.relu(_conv1(P, pre + ated + ".0.weight", g))))
+    return out
+
+
+def geometry_mlp(P, pe, fused, weight, pre="mlp_geo."):
+    """MLPUNetFusion.forward for the shipped config (src/utils.py:633-649, 709-719, 744-779, 822-880), one view:
+    layers1 with skips at 0 and 2, mean / var pooling with the pixel weight, layers2.  -> (N,2) [sdf_pred, rad], latent (N,128)."""
+    x = pe
+    for i in range(4):
+        if i == 0:
+            x = torch.cat([x, fused[0]], -1)
+        elif i == 2:
+            x = torch.cat([x, fused[1]], -1)
+        x = _linear_wn(P, f"{pre}layers1.layers.{i}.linear", x)
+        if i != 3:
+            x = _softplus(x)
+    mean = weight * x
+    var = weight * (x - mean) ** 2
+    latent = torch.cat([mean, var], -1)
+    x = latent
+    for i in range(3):
+        x = _linear_wn(P, f"{pre}layers2.layers.{i}.linear", x)
+        if i != 2:
+            x = _softplus(x)
+    return x, latent
+
+
+def texture_vertex_table(P, vert_xy, feat_tex, img, pre="tex_vis_fusion."):
+    """Per-frame part of TexVisFusion.forward (src/networks.py:270-279): (NV,29) = [img 3 | tex 8 | global 18]."""
+    def stack(x, name):
+        hw = x.shape[-1]
+        x = F.conv2d(x, P[pre + name + ".0.weight"], padding=1)
+        x = torch.relu(F.layer_norm(x, [hw, hw], P[pre + name + ".1.weight"], P[pre + name + ".1.bias"], 1e-6))
+        x = F.conv2d(x, P[pre + name + ".3.weight"], padding=1)
+        x = torch.relu(F.layer_norm(x, [hw, hw], P[pre + name + ".4.weight"], P[pre + name + ".4.bias"], 1e-6))
+        return F.adaptive_avg_pool2d(x, 3).reshape(1, x.shape[1], 9)
+
+    gf = torch.cat([stack(img, "fconv4"), stack(feat_tex, "fconv3")], -1)  # (1, NV, 18): the conv stacks have NV output channels
+    x = F.conv1d(gf, P[pre + "fconv_gt.0.weight"], padding=1)
+    x = torch.relu(F.layer_norm(x, [18], P[pre + "fconv_gt.1.weight"], P[pre + "fconv_gt.1.bias"], 1e-6))
+    x = F.conv1d(x, P[pre + "fconv_gt.3.weight"], padding=1)
+    x = torch.relu(F.layer_norm(x, [18], P[pre + "fconv_gt.4.weight"], P[pre + "fconv_gt.4.bias"], 1e-6))
+    return torch.cat([sample_map(img, vert_xy), sample_map(feat_tex, vert_xy), x[0]], 1)
+
+
+def texture_fusion(P, table29, tex_xy, img_xy, idx, vert_vis, q_vis, latent24, pre="tex_vis_fusion."):
+    """Per-sample part of TexVisFusion.forward (src/networks.py:281-293) -> (N,40); at one view the colour is its first 3 channels
+    (IBRRenderingHead is a softmax over a single view: src/model.py:1613, 1635)."""
+    nn_f, tw_f, vis_nn, vis_tw = _nearest_rows(table29, vert_vis, idx)
+    q = torch.cat([img_xy, tex_xy], 1)
+    tail = [q_vis, vis_nn, vis_tw]
+    parts = [q, nn_f[:, :11], tw_f[:, :11], nn_f[:, 11:], tw_f[:, 11:], latent24]
+    a = torch.sigmoid(_conv1(P, pre + "fconv_at.2.weight", torch.relu(_conv1(P, pre + "fconv_at.0.weight", torch.cat(parts + tail, 1)))))
+    g = torch.cat([p * a[:, j:j + 1] for j, p in enumerate(parts)] + tail, 1)
+    return _conv1(P, pre + "fconv.2.weight", torch.relu(_conv1(P, pre + "fconv.0.weight", g)))
+
+
+def networks_at(P, frame, pts, q_sdf, q_vis, knn, noise=None, sp_args=None):
+    """VANeRF.query + query_color + eval_func at N given points -> (N,5) [alpha, sdf, r, g, b] with gradient.
+    frame: dict(cam, img (1,3,H,W), feat_geo [2 maps], feat_tex, fg_mask (1,1,H,W), verts (NV,3), vert_vis (NV,), kpt3d, extrin,
+    table29 (optional, from texture_vertex_table)); q_sdf (N,), q_vis (N,) in {0,1}, knn (N,) int64, noise (N,) or None."""
+    sp = sp_args or {"sp_level": 3, "scale": 1.0, "sigma": 0.1}
+    cam = frame["cam"]
+    xy, z = project(pts, cam)
+    eps = 1e-2
+    inside = ((xy >= -1.0 - eps) & (xy <= 1.0 + eps)).all(-1, keepdim=True) & (z >= -1.0)
+    mask = (inside & (sample_map(frame["fg_mask"].float(), xy) > 0.1)).float()                      # (N,1)
+    xyz = 0.5 * torch.cat([xy, z], -1) + 0.5
+    pw = torch.sigmoid(5.0 * (torch.min(xyz, 1.0 - xyz) / 0.1 - 1.0)).prod(-1, keepdim=True) * mask
+    weight = pw / (pw + 1e-6)                                                                       # one view: pw / (sum over views + 1e-6)
+    vert_xy = project_vertices(frame["verts"], cam)
+    vis = frame["vert_vis"].float()
+    qs, qv = q_sdf.view(-1, 1).float(), q_vis.view(-1, 1).float()
+    pix = [sample_map(f, xy) for f in frame["feat_geo"]]
+    fused = geo_fusion(P, frame["feat_geo"], pix, vert_xy, knn, vis, qv, qs)
+    pe = positional_encoding(pts, frame["kpt3d"], frame["extrin"], sp["sp_level"], sp["scale"], sp["sigma"])
+    geo, latent = geometry_mlp(P, pe, fused, weight)
+    latent24 = F.linear(latent, P["ibr_compress_gfeat.weight"], P["ibr_compress_gfeat.bias"])
+    table29 = frame.get("table29")
+    if table29 is None:
+        table29 = texture_vertex_table(P, vert_xy, frame["feat_tex"], frame["img"])
+    rgb = texture_fusion(P, table29, sample_map(frame["feat_tex"], xy), sample_map(frame["img"], xy), knn, vis, qv, latent24)[:, :3]
+    # eval_func (src/model.py:1140-1160)
+    sdf = mask * geo[:, 0:1] + (1.0 - mask) * (0.1 / cam["nml_scale"])
+    rad = geo[:, 1:2] if noise is None else geo[:, 1:2] + noise.view(-1, 1)
+    return torch.cat([mask * torch.relu(rad), sdf, rgb], -1)
+
+
+def composite(P, rgba, z, mesh_sdf):
+    """sdf_activation + rgba2out (src/model.py:879-882, 1464-1494): rgba (R,S,5), z (R,S), mesh_sdf (R,S) ->
+    colour (R,3), depth, alpha, sdf (R,)."""
+    beta = torch.clamp(P["sigmoid_beta"], min=2e-3)
+    sigma = torch.sigmoid(-(rgba[..., 0] + mesh_sdf) / beta) / beta
+    dist = torch.cat([z[:, 1:] - z[:, :-1], 1e10 * torch.ones_like(z[:, :1])], -1)
+    c = 1.0 - torch.exp(-sigma * dist)
+    w = c * torch.cumprod(torch.cat([torch.ones_like(c[:, :1]), 1.0 - c[:, :-1]], -1), -1)
+    acc = w.sum(-1)
+    return (rgba[..., 2:] * w[..., None]).sum(-2), (z * w).sum(-1) / (acc + 1e-8), acc, (rgba[..., 1] * w).sum(-1) / (acc + 1e-8)
+
+
+def straight_through(value, graph):
+    """HIP value, this module's gradient."""
+    return graph + (value - graph).detach()
