@@ -27,3 +27,43 @@ def gather_image(tile, height, width, world, group=None):
     full = torch.empty(world * tile.shape[0], tile.shape[1], dtype=tile.dtype, device=tile.device)
     dist.all_gather_into_tensor(full, tile.contiguous(), group=group)
     return deinterleave(full, height, width, world, tile.shape[1])
+
+
+def all_reduce_gradients(parameters, world, bucket_bytes=32 << 20, group=None):
+    """Data-parallel training (BASELINE config 5: one process per GPU, each with its own source frame / patch): average the gradients
+    over the ranks after backward().  Gradients are flattened into a few large buckets -- xGMI is point-to-point, a ring all-reduce is
+    bound per link, so few large calls beat one call per parameter (the renderer's hot parameters are ~100 small tensors; the two
+    encoders ~200 more) -- reduced with one all_reduce each and copied back.  Parameters without a gradient on this rank (e.g. the
+    IBR head at one source view) take part as zeros so that every rank issues the same collectives."""
+    if world == 1:
+        return 0
+    import torch.distributed as dist
+    params = [p for p in parameters if p.requires_grad]
+    calls, bucket, size = 0, [], 0
+
+    def flush():
+        nonlocal calls, bucket, size
+        if not bucket:
+            return
+        flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in bucket])
+        dist.all_reduce(flat, group=group)
+        flat /= world
+        off = 0
+        for p in bucket:
+            n = p.numel()
+            if p.grad is None:
+                p.grad = flat[off:off + n].view_as(p).clone()
+            else:
+                p.grad.copy_(flat[off:off + n].view_as(p))
+            off += n
+        calls += 1
+        bucket, size = [], 0
+
+    for p in params:
+        nbytes = p.numel() * p.element_size()
+        if bucket and (size + nbytes > bucket_bytes or p.dtype != bucket[0].dtype):
+            flush()
+        bucket.append(p)
+        size += nbytes
+    flush()
+    return calls
