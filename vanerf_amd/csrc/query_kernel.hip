@@ -4,10 +4,11 @@
 //
 // One wave = 32 samples.  Lane l works on sample j = l & 31; the two lanes j and j + 32 that share
 // a sample split every K dimension between them (half h = l >> 5), see layer_spec.h.  All 20 dense
-// layers run as v_mfma_f32_32x32x2_f32 chains whose accumulators stay in registers from the
-// bilinear gathers to the final (alpha, sdf, rgb) store: activations never touch LDS or HBM.
-// No LDS at all: key points come through the scalar cache; the 1-NN vertex index arrives from vanerf_mesh_query_accel.
-// Weights stream from L2 as pre-permuted MFMA A-fragments (weights_pack.cpp).
+// layers run as MFMA chains -- query_kernel<0>: v_mfma_f32_32x32x2_f32 on fp32 operands; query_kernel<1>:
+// v_mfma_f32_32x32x16_bf16 on split (hi + lo) operands, fp32 accumulate -- whose accumulators stay in registers
+// from the bilinear gathers to the final (alpha, sdf, rgb) store: activations never touch LDS or HBM.
+// No LDS at all: key points come through the scalar cache (fp32 kernel) or live in registers (bf16 kernel); the 1-NN
+// vertex index arrives from vanerf_mesh_query_accel.  Weights stream from L2 as pre-permuted MFMA A-fragments (weights_pack.cpp).
 //
 // Built with -ffp-contract=off: the integer-valued outputs (1-NN index) depend on fp32 compare
 // results and must match oracle/mesh_oracle.c bit for bit; fused multiply-adds are spelled fmaf().
