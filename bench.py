@@ -118,7 +118,7 @@ def main():
 
     def step(record=None):
         out = renderer.render_pass(weights, fdat, frame["cam_tar"], frame["bounds"], 0, rows[0], 1, W, rows[2], S, S,
-                                   kernel_events=record, y_step=rows[1])
+                                   kernel_events=record, y_step=rows[1], y_block=rows[3])
         tile = out["color_fine"]
         if world > 1:
             if args.backend == "nccl":
@@ -196,11 +196,11 @@ def main():
                             "frac_pixels_above_1e-4": (err.max(1)[0] > 1e-4).float().mean().item(), "pixels": int(idx.numel())}
         result["speedup_vs_cpu"] = result["value"] / base["value"]
     if world > 1:  # the gathered, de-interleaved image must contain this rank's own rows at their place
-        from vanerf_amd.parallel import deinterleave
+        from vanerf_amd.parallel import deinterleave, rank_rows
         full_img = deinterleave(img, H, W, world)
         own = step()
         own = own.view(world, rows[2], W, 3)[rank] if own.shape[0] == H * W else own.view(rows[2], W, 3)
-        assert torch.equal(full_img[rows[0]::rows[1]], own), "gathered image does not contain this rank's rows"
+        assert torch.equal(full_img[rank_rows(H, world, rank).to(full_img.device)], own), "gathered image does not contain this rank's rows"
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define VANERF_ABI_VERSION 2
+#define VANERF_ABI_VERSION 3
 
 #define VANERF_OK 0
 #define VANERF_EINVAL (-22)
@@ -110,14 +110,15 @@ int vanerf_weights_short_groups(const VanerfWeights* w, uint64_t* count);
 int vanerf_weights_pack_host(const VanerfWeightTable* w, float* out, int64_t cap, int64_t* n_out, unsigned* offsets);
 
 /* a1-a4  Pixel grid, ray generation, bbox clipping, coarse depths (src/model.py:1191-1238, 1496-1570).
- *   grid: x = x0 + ix*step_x, y = y0 + iy*step_y for iy < ny (outer), ix < nx (inner); R = nx*ny rays
- *         (the reference's strided grid has step_x = step_y = 2^(level-1), model.py:1194; row-interleaved multi-GPU shards use step_y = N)
+ *   grid: x = x0 + ix*step_x, y = y0 + (iy / y_block)*step_y + (iy % y_block)*step_x for iy < ny (outer), ix < nx (inner); R = nx*ny rays
+ *         (the reference's strided grid: step_x = step_y = 2^(level-1), y_block = 1, model.py:1194; a multi-GPU shard takes blocks of
+ *          y_block = 8 consecutive rows, step_x = 1, step_y = 8 N, y0 = 8 rank: 8x8 pixel tiles stay whole, the load stays balanced)
  *   invK_T[9]: inverse(K[:3,:3]) transposed, row-major (host computed, as th.inverse at model.py:1208)
  *   RT[12]: target [R|t] rows 0..2;  bounds[6] = {min xyz, max xyz} (host values)
  *   t_lin[S]: th.linspace(0, 1, S) (device; computed by the caller so that it is bit-identical to torch's)
  *   outputs: index[R] (int64 pixel index x + y*W), rays_d[R][3], cam_pos[3] (device), near[R], far[R], hit[R] (u8),
  *            z[R][S] coarse depths (uniform=True: t_lin; else stratified with jitter[R][S] in [0,1) drawn by the caller) */
-int vanerf_ray_setup(int x0, int y0, int step_x, int step_y, int nx, int ny, int width, const float* invK_T, const float* RT,
+int vanerf_ray_setup(int x0, int y0, int step_x, int step_y, int y_block, int nx, int ny, int width, const float* invK_T, const float* RT,
                      float znear, float zfar, const float* bounds, int S, const float* t_lin, const float* jitter,
                      int64_t* index, float* rays_d, float* cam_pos, float* near, float* far, uint8_t* hit, float* z,
                      void* stream);

@@ -8,7 +8,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from vanerf_amd.parallel import deinterleave, gather_image, shard_rows
+from vanerf_amd.parallel import deinterleave, gather_image, rank_rows, shard_rows
 
 H, W = 16, 6
 
@@ -20,8 +20,7 @@ def _image():
 def _worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    y0, ystep, ny = shard_rows(H, world, rank)
-    rows = torch.arange(ny) * ystep + y0
+    rows = rank_rows(H, world, rank)
     tile = _image()[rows].reshape(-1, 3)  # what this rank would have rendered: (rows * W, 3)
     full = gather_image(tile, H, W, world)
     t = torch.tensor([float(rank + 1)])
@@ -30,31 +29,52 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def _run_ranks(target, world=2, attempts=3):
+    """Spawns `world` gloo ranks; a rendezvous on a just-probed free port can lose a race with another process: retried."""
+    import queue as _queue
+    for attempt in range(attempts):
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        procs = [ctx.Process(target=target, args=(r, world, port, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        try:
+            res = [q.get(timeout=120) for _ in procs]
+        except _queue.Empty:
+            res = None
+        for p in procs:
+            p.join(60)
+            if p.is_alive():
+                p.kill()
+        if res is not None and all(p.exitcode == 0 for p in procs):
+            return sorted(res, key=lambda t: t[0])
+    raise AssertionError("the gloo ranks did not finish")
+
+
 def test_two_rank_gather():
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    res = sorted(q.get(timeout=120) for _ in procs)
-    for p in procs:
-        p.join(60)
-        assert p.exitcode == 0
-    assert res == [(0, True, 2.0), (1, True, 2.0)]
+    assert _run_ranks(_worker) == [(0, True, 2.0), (1, True, 2.0)]
 
 
 def test_shard_rows_cover_image_once():
-    for world in (1, 2, 4, 8):
-        seen = torch.zeros(512, dtype=torch.int32)
-        for rank in range(world):
-            y0, step, ny = shard_rows(512, world, rank)
-            seen[torch.arange(ny) * step + y0] += 1
-        assert (seen == 1).all()
-    tiles = [(_image()[torch.arange(H // 4) * 4 + r]).reshape(-1, 3) for r in range(4)]
-    assert torch.equal(deinterleave(torch.cat(tiles, 0), H, W, 4), _image())
+    for height in (512, 16, 12):  # 12 rows on 4 ranks: not a multiple of 8 * world -> single interleaved rows
+        for world in (1, 2, 4, 8):
+            if height % world:
+                continue
+            seen = torch.zeros(height, dtype=torch.int32)
+            for rank in range(world):
+                y0, step, ny, yb = shard_rows(height, world, rank)
+                assert ny == height // world and yb in (1, 8)
+                seen[rank_rows(height, world, rank)] += 1
+            assert (seen == 1).all()
+    # blocks of 8 rows stay together (8x8 pixel tiles of the mesh query), dealt round robin
+    assert rank_rows(512, 8, 3)[:10].tolist() == [24, 25, 26, 27, 28, 29, 30, 31, 88, 89]
+    for hh, world in ((H, 2), (12, 4), (64, 4)):
+        img = torch.arange(hh * W * 3, dtype=torch.float32).view(hh, W, 3)
+        tiles = [img[rank_rows(hh, world, r)].reshape(-1, 3) for r in range(world)]
+        assert torch.equal(deinterleave(torch.cat(tiles, 0), hh, W, world), img)
 
 
 def _grad_worker(rank, world, port, q):
@@ -73,18 +93,7 @@ def _grad_worker(rank, world, port, q):
 
 def test_two_rank_gradient_average():
     """all_reduce_gradients: bucketed all-reduce == the mean of the per-rank gradients, same result and same number of calls on every rank."""
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    res = sorted((q.get(timeout=120) for _ in procs), key=lambda t: t[0])
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    res = _run_ranks(_grad_worker)
     torch.manual_seed(0)
     net = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.Linear(5, 3), torch.nn.Linear(3, 2))
     want = None

@@ -12,7 +12,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int64, c_uint
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libvanerf_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 NUM_LAYERS = 20
 
 if not os.path.exists(LIB_PATH):
@@ -61,7 +61,7 @@ _SIGS = {
     "vanerf_weights_free": (c_int, [c_void_p]),
     "vanerf_weights_short_groups": (c_int, [c_void_p, POINTER(c_uint64)]),
     "vanerf_weights_pack_host": (c_int, [POINTER(VanerfWeightTable), _FP, c_int64, POINTER(c_int64), POINTER(c_uint)]),
-    "vanerf_ray_setup": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, POINTER(c_float), POINTER(c_float), c_float, c_float,
+    "vanerf_ray_setup": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, POINTER(c_float), POINTER(c_float), c_float, c_float,
                                  POINTER(c_float), c_int, _FP, _FP, _FP, _FP, _FP, _FP, _FP, _FP, _FP, c_void_p]),
     "vanerf_ray_setup_pixels": (c_int, [_FP, c_int, c_int, POINTER(c_float), POINTER(c_float), c_float, c_float, POINTER(c_float), c_int, _FP, _FP,
                                         _FP, _FP, _FP, _FP, _FP, _FP, _FP, c_void_p]),

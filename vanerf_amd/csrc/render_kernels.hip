@@ -12,7 +12,7 @@ using namespace vanerf;
 namespace {
 
 struct RayParams {
-    int x0, y0, step_x, step_y, nx, ny, width;
+    int x0, y0, step_x, step_y, y_block, nx, ny, width;
     const int32_t* pixels; // optional explicit (x, y) list of nx*ny pixels (training patches), else the regular grid
     float invK_T[9];
     float RT[12];
@@ -92,7 +92,7 @@ __global__ void ray_setup_kernel(const RayParams P)
     if (r >= R) return;
     const int ix = r % P.nx, iy = r / P.nx;
     const int gxi = P.pixels ? P.pixels[2 * r] : P.x0 + ix * P.step_x;
-    const int gyi = P.pixels ? P.pixels[2 * r + 1] : P.y0 + iy * P.step_y;
+    const int gyi = P.pixels ? P.pixels[2 * r + 1] : P.y0 + (iy / P.y_block) * P.step_y + (iy % P.y_block) * P.step_x;
     P.index[r] = (int64_t)gxi + (int64_t)gyi * P.width;
     const float gx = (float)gxi, gy = (float)gyi;
     const float* K = P.invK_T; // row-major 3x3: c_j = gx*K[0][j] + gy*K[1][j] + K[2][j]
@@ -285,17 +285,17 @@ __global__ __launch_bounds__(IM_BLOCK) void importance_merge_kernel(const float*
 
 } // namespace
 
-static void ray_setup_impl(const int32_t* pixels, int x0, int y0, int step_x, int step_y, int nx, int ny, int width, const float* invK_T,
+static void ray_setup_impl(const int32_t* pixels, int x0, int y0, int step_x, int step_y, int y_block, int nx, int ny, int width, const float* invK_T,
                            const float* RT, float znear, float zfar, const float* bounds, int S, const float* t_lin, const float* jitter,
                            int64_t* index, float* rays_d, float* cam_pos, float* near, float* far, uint8_t* hit, float* z, void* stream);
 
-extern "C" int vanerf_ray_setup(int x0, int y0, int step_x, int step_y, int nx, int ny, int width, const float* invK_T, const float* RT,
+extern "C" int vanerf_ray_setup(int x0, int y0, int step_x, int step_y, int y_block, int nx, int ny, int width, const float* invK_T, const float* RT,
                                 float znear, float zfar, const float* bounds, int S, const float* t_lin, const float* jitter,
                                 int64_t* index, float* rays_d, float* cam_pos, float* near, float* far, uint8_t* hit, float* z,
                                 void* stream)
 {
     return guarded([&] {
-        ray_setup_impl(nullptr, x0, y0, step_x, step_y, nx, ny, width, invK_T, RT, znear, zfar, bounds, S, t_lin, jitter, index, rays_d,
+        ray_setup_impl(nullptr, x0, y0, step_x, step_y, y_block, nx, ny, width, invK_T, RT, znear, zfar, bounds, S, t_lin, jitter, index, rays_d,
                        cam_pos, near, far, hit, z, stream);
     });
 }
@@ -306,22 +306,22 @@ extern "C" int vanerf_ray_setup_pixels(const int32_t* pixels_xy, int n_rays, int
 {
     return guarded([&] {
         if (!pixels_xy) throw_error("vanerf_ray_setup_pixels: null pixel list");
-        ray_setup_impl(pixels_xy, 0, 0, 1, 1, n_rays, 1, width, invK_T, RT, znear, zfar, bounds, S, t_lin, jitter, index, rays_d, cam_pos,
+        ray_setup_impl(pixels_xy, 0, 0, 1, 1, 1, n_rays, 1, width, invK_T, RT, znear, zfar, bounds, S, t_lin, jitter, index, rays_d, cam_pos,
                        near, far, hit, z, stream);
     });
 }
 
-static void ray_setup_impl(const int32_t* pixels, int x0, int y0, int step_x, int step_y, int nx, int ny, int width, const float* invK_T,
+static void ray_setup_impl(const int32_t* pixels, int x0, int y0, int step_x, int step_y, int y_block, int nx, int ny, int width, const float* invK_T,
                            const float* RT, float znear, float zfar, const float* bounds, int S, const float* t_lin, const float* jitter,
                            int64_t* index, float* rays_d, float* cam_pos, float* near, float* far, uint8_t* hit, float* z, void* stream)
 {
     {
         if (!invK_T || !RT || !bounds || !t_lin || !index || !rays_d || !cam_pos || !near || !far || !hit || !z)
             throw_error("vanerf_ray_setup: null argument");
-        if (nx <= 0 || ny <= 0 || step_x <= 0 || step_y <= 0 || S < 2 || width <= 0)
+        if (nx <= 0 || ny <= 0 || step_x <= 0 || step_y <= 0 || y_block <= 0 || S < 2 || width <= 0)
             throw_error("vanerf_ray_setup: bad grid (nx=%d ny=%d step=%d,%d S=%d)", nx, ny, step_x, step_y, S);
         RayParams P;
-        P.x0 = x0; P.y0 = y0; P.step_x = step_x; P.step_y = step_y; P.nx = nx; P.ny = ny; P.width = width; P.pixels = pixels;
+        P.x0 = x0; P.y0 = y0; P.step_x = step_x; P.step_y = step_y; P.y_block = y_block; P.nx = nx; P.ny = ny; P.width = width; P.pixels = pixels;
         std::copy_n(invK_T, 9, P.invK_T);
         std::copy_n(RT, 12, P.RT);
         std::copy_n(bounds, 6, P.bounds);

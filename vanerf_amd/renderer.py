@@ -446,9 +446,10 @@ def ray_bbox(bounds, orig, dirs):
     return near, far, hit
 
 
-def ray_setup(cam_tar, bounds, x0, y0, step, nx, ny, S, jitter=None, device=None, y_step=None, pixels=None):
+def ray_setup(cam_tar, bounds, x0, y0, step, nx, ny, S, jitter=None, device=None, y_step=None, pixels=None, y_block=1):
     """Pixel grid + rays + bbox clip + coarse depths (src/model.py:1191-1238, 1496-1570).
-    pixels: optional explicit (R,2) int32 device tensor of (x, y) (training patches); then nx*ny must equal R."""
+    pixels: optional explicit (R,2) int32 device tensor of (x, y) (training patches); then nx*ny must equal R.
+    y_step, y_block: rows are y0 + (iy // y_block) * y_step + (iy % y_block) * step (multi-GPU shards: blocks of y_block rows)."""
     dev = device or bounds.device
     K = cam_tar["K"].detach().to("cpu", torch.float32)
     RT = cam_tar["RT"].detach().to("cpu", torch.float32)
@@ -468,7 +469,7 @@ def ray_setup(cam_tar, bounds, x0, y0, step, nx, ny, S, jitter=None, device=None
         assert pixels.shape == (R, 2)
         check(lib.vanerf_ray_setup_pixels(_ptr(pixels, torch.int32), R, int(cam_tar["width"]), *cam_args))
     else:
-        check(lib.vanerf_ray_setup(int(x0), int(y0), int(step), int(y_step or step), int(nx), int(ny), int(cam_tar["width"]), *cam_args))
+        check(lib.vanerf_ray_setup(int(x0), int(y0), int(step), int(y_step or step), int(y_block), int(nx), int(ny), int(cam_tar["width"]), *cam_args))
     return dict(index=index, rays_d=rays_d, cam_pos=cam_pos, near=near, far=far, hit=hit, z=z)
 
 
@@ -484,7 +485,7 @@ def sample_points(rays_d, cam_pos, z):
 # ------------------------------------------------------------------------------------------------
 def render_pass(weights, frame, cam_tar, bounds, x0, y0, step, nx, ny, sample_per_ray_c=64, sample_per_ray_f=64, fine=True,
                 jitter=None, u=None, noise_std=0.0, generator=None, debug=False, kernel_events=None, y_step=None, reuse_coarse=True,
-                pixels=None):
+                pixels=None, y_block=1):
     """Returns flat per-ray tensors: color/depth/alpha (coarse), color_fine/depth_fine/alpha_fine/sdf (fine), index, z, z_fine.
 
     reuse_coarse: the fine composite needs the networks at the Sc coarse and the Sf new depths of every ray.  The reference
@@ -493,7 +494,8 @@ def render_pass(weights, frame, cam_tar, bounds, x0, y0, step, nx, ny, sample_pe
     With per-sample noise (training, rand_noise_std > 0) the reference draws fresh noise for the re-evaluated coarse
     samples, so re-use is switched off there."""
     Sc, Sf = int(sample_per_ray_c), int(sample_per_ray_f)
-    rays = ray_setup(cam_tar, bounds, x0, y0, step, nx, ny, Sc, jitter=jitter, device=frame.verts3.device, y_step=y_step, pixels=pixels)
+    rays = ray_setup(cam_tar, bounds, x0, y0, step, nx, ny, Sc, jitter=jitter, device=frame.verts3.device, y_step=y_step, pixels=pixels,
+                     y_block=y_block)
     R = nx * ny
     if noise_std > 0.0:
         reuse_coarse = False
