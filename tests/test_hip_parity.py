@@ -360,6 +360,27 @@ def test_full_view_properties(R, sd_full, precision):
     assert torch.equal(part["color_fine"], full["color_fine"].view(512, 334, 3)[100:164].reshape(-1, 3))
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_config1_128x128_32_samples(R, sd_full, precision):
+    """BASELINE config 1 (single 128x128 view, 32 samples per ray): a strided 16x16 slice against the oracle, the rest by properties."""
+    frame = _frame(7, 128, 20.0)
+    fdat = _frame_data(R, sd_full, frame)
+    w = R.PackedWeights(sd_full, mode=precision)
+    full = R.render_pass(w, fdat, frame["cam_tar"], frame["bounds"], 0, 0, 1, 128, 128, 32, 32)
+    assert full["color_fine"].shape == (128 * 128, 3) and torch.isfinite(full["color_fine"]).all()
+    assert (full["z_fine"][:, 1:] >= full["z_fine"][:, :-1]).all()
+    out = R.render_pass(w, fdat, frame["cam_tar"], frame["bounds"], 3, 5, 8, 16, 16, 32, 32)
+    gy, gx = torch.meshgrid(torch.arange(16) * 8 + 5, torch.arange(16) * 8 + 3, indexing="ij")
+    fr = dict(frame)
+    fr["out_hw"] = (16, 16)
+    ref = orc.batch_render(sd_full, fr, 1, None, 32, 32, grids=torch.stack([gx, gy], -1).view(1, -1, 2))
+    assert torch.equal(out["index"].cpu(), ref["index"][0])
+    idx = out["index"]
+    assert torch.equal(out["color_fine"], full["color_fine"][idx])  # ray independence: the slice is part of the full view
+    assert_close_frac(out["color_fine"].cpu().view(16, 16, 3).permute(2, 0, 1), ref["tex_fg_fine"][0], TOL, 2 * OUTLIERS, "tex_fg_fine")
+    assert_close_frac(out["alpha_fine"].cpu().view(16, 16), ref["alpha_fine"][0], TOL, 2 * OUTLIERS, "alpha_fine")
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # the reference-shaped interface (vanerf_amd.model.VANeRF) on the GPU, against the fixtures captured from the reference
 # ---------------------------------------------------------------------------------------------------------------------
@@ -460,11 +481,12 @@ def test_model_training_patch_and_noise(net):
     assert out["tar_alpha"].shape == (1, 1, 64, 64) if "tar_alpha" in out else True
 
 
-def test_edge_cases_and_config3(R, sd_full):
-    """Ragged / tiny / empty launches and the 128+128-sample configuration (BASELINE config 3)."""
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_edge_cases_and_config3(R, sd_full, precision):
+    """Ragged / tiny / empty launches and the 128+128-sample configuration (BASELINE config 3), both MFMA precisions."""
     frame = _frame(5, 64, 70.0, True)
     fdat = _frame_data(R, sd_full, frame)
-    w = R.PackedWeights(sd_full)
+    w = R.PackedWeights(sd_full, mode=precision)
     # empty and single-sample launches
     e3, e1 = torch.empty(0, 3, device="cuda"), torch.empty(0, device="cuda")
     assert R.query_samples(w, fdat, e3, e1, torch.empty(0, dtype=torch.uint8, device="cuda"), torch.empty(0, dtype=torch.int32, device="cuda")).shape == (0, 5)

@@ -491,16 +491,31 @@ __global__ __launch_bounds__(BLOCK, MODE == 1 ? VANERF_WAVES_PER_SIMD_B : VANERF
         for (int i = 0; i < PE_KPT_PER_HALF; ++i) { const float4 k = kpl[i]; kpx[i] = k.x; kpy[i] = k.y; kpz[i] = k.z; }
     }
     unsigned short_groups = 0;
+    // The six per-sample inputs of a group are fetched one group ahead (its index is known from the early claim): their HBM latency
+    // is otherwise the first thing a group waits for, and a single wave per SIMD (bf16 kernel) has nobody to hide it.
+    struct SampleIn { float px, py, pz, sdf; int knn; unsigned char vis; };
+    auto fetch = [&](unsigned grp) {
+        const long long sr = (long long)grp * 32 + j;
+        const long long sc = sr < P.n ? sr : P.n - 1; // also covers a claim beyond the last group (never used)
+        SampleIn in;
+        in.px = P.pts[3 * sc]; in.py = P.pts[3 * sc + 1]; in.pz = P.pts[3 * sc + 2];
+        in.sdf = P.qsdf[sc]; in.knn = P.knn_in[sc]; in.vis = P.qvis[sc];
+        return in;
+    };
     unsigned g_next = claim();
+    SampleIn in_next = fetch(g_next);
     while (g_next < (unsigned)ngroups) {
         const long long g = g_next;
+        const SampleIn in = in_next;
         g_next = claim();
+        in_next = fetch(g_next);
+        __builtin_amdgcn_sched_barrier(0x000F); // keep these loads here (the scheduler sinks loads to their first use)
         const long long s_raw = g * 32 + j;
         const bool live = s_raw < P.n;
         const long long s = live ? s_raw : P.n - 1;
-        const float px = P.pts[3 * s], py = P.pts[3 * s + 1], pz = P.pts[3 * s + 2];
-        const float q_sdf = P.qsdf[s];
-        const float q_vis = P.qvis[s] ? 1.0f : 0.0f;
+        const float px = in.px, py = in.py, pz = in.pz;
+        const float q_sdf = in.sdf;
+        const float q_vis = in.vis ? 1.0f : 0.0f;
 
         // ---- projection into the source view, validity mask, boundary weight (src/model.py:780-821) ----
         float vx = fmaf(pz, F.KRT[2], fmaf(py, F.KRT[1], px * F.KRT[0])) + F.KRT[3];
@@ -527,7 +542,7 @@ __global__ __launch_bounds__(BLOCK, MODE == 1 ? VANERF_WAVES_PER_SIMD_B : VANERF
 
         STAMP(0); // front end
         // ---- 1-NN vertex (src/networks.py:27-33): found by vanerf_mesh_query_accel (same pass as the SDF) ----------
-        const int nn_idx = P.knn_in[s];
+        const int nn_idx = in.knn;
         const int tw_idx = nn_idx >= VANERF_NV_HAND ? nn_idx - VANERF_NV_HAND : nn_idx + VANERF_NV_HAND;
         const float vis_nn = ld_off<float>(F.vert_vis, 4u * nn_idx), vis_tw = ld_off<float>(F.vert_vis, 4u * tw_idx);
         const float sc0 = h ? q_vis : q_sdf;   // k-pair (sdf | qvis)
