@@ -181,9 +181,18 @@ def test_importance_merge_bit_exact_idx(R, golden):
     # random u (training): unsorted draws
     u = torch.rand(Rn, 32, generator=g)
     want_u = orc.importance_sample(contrib[None, :, 1:-1], z_mid[None], 32, uniform=False, u=u[None])
-    z_new_u, z_fine_u, _ = R.importance_merge(dev(contrib), dev(z), 32, u=dev(u))
+    z_new_u, z_fine_u, src_u = R.importance_merge(dev(contrib), dev(z), 32, u=dev(u))
     assert (z_new_u.cpu() - want_u[0]).abs().max() <= 1e-6
     assert (z_fine_u.cpu() - torch.sort(torch.cat([z, want_u[0]], -1), -1)[0]).abs().max() <= 1e-6
+    # the origin map names, for every merged depth, the coarse sample (>= 0) or the draw (~index) it is -- each exactly once -- and the merge
+    # is stable: coarse samples keep their order and come first on ties, equal draws keep their draw order
+    su, zfu = src_u.cpu().long(), z_fine_u.cpu()
+    both = torch.cat([z, z_new_u.cpu()], -1)
+    col = torch.where(su >= 0, su, S + (-su - 1))
+    assert torch.equal(torch.gather(both, 1, col), zfu) and torch.equal(torch.sort(col, -1)[0], torch.arange(S + 32).expand(Rn, -1))
+    assert (zfu[:, 1:] >= zfu[:, :-1]).all()
+    tie = zfu[:, 1:] == zfu[:, :-1]
+    assert (col[:, 1:][tie] > col[:, :-1][tie]).all()
     # the golden vector from the reference (16 samples)
     gi = golden("importance")
     zn, zf2, _, idx2 = R.importance_merge(dev(gi["contrib"][0].contiguous()), dev(gi["z"][0].contiguous()), 16, want_idx=True)

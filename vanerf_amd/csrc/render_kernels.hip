@@ -467,6 +467,94 @@ extern "C" int vanerf_composite_merged(const float* rgba_c, const float* mesh_sd
     });
 }
 
+// importance_sample + sort-merge with one WAVE per ray (Sc, Sf <= 64: lane i holds coarse sample i and new sample i).  The rows of a ray
+// are read and written coalesced (one thread per ray touched 64 cache lines per access), the pdf total is a wave reduction and the cdf
+// a wave scan in fp64 (the sequential fp64 sums they replace differ from them by ~1e-16 relative before the rounding to fp32), each lane
+// draws one sample by binary search in the LDS copy of the cdf, and the merge is by rank: coarse sample a goes to a + #(new < z_a), new
+// sample b to b + #(coarse <= z_b) -- the stable merge of the serial kernel (coarse first on ties).  Unsorted draws (random u, or a last-bit
+// inversion) are rank-sorted first, stably, like the insertion sort they replace.
+constexpr int IW_RAYS = 4; // waves (rays) per block
+__global__ __launch_bounds__(64 * IW_RAYS) void importance_merge_wave_kernel(const float* __restrict__ contrib, const float* __restrict__ z,
+                                                                             const float* __restrict__ u, const float* __restrict__ t_lin, int R,
+                                                                             int Sc, int Sf, float* __restrict__ z_new, float* __restrict__ z_fine,
+                                                                             int32_t* __restrict__ src, int32_t* __restrict__ idx_out)
+{
+    __shared__ float s_all[IW_RAYS][6][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int r = blockIdx.x * IW_RAYS + wv;
+    if (r >= R) return; // whole wave
+    float* cdf = s_all[wv][0];
+    float* zmid = s_all[wv][1];
+    float* smp = s_all[wv][2];   // new samples in draw order
+    float* srt = s_all[wv][3];   // ... sorted
+    int* perm = reinterpret_cast<int*>(s_all[wv][4]);
+    float* zc = s_all[wv][5];    // coarse depths
+    const int nb = Sc - 2;
+    const float ci = lane < Sc ? contrib[(size_t)r * Sc + lane] : 0.0f;
+    const float zi = lane < Sc ? z[(size_t)r * Sc + lane] : INFINITY;
+    const bool inner = lane >= 1 && lane <= nb;
+    double tot = inner ? (double)(ci + 1e-5f) : 0.0;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) tot += __shfl_xor(tot, d);
+    const float sum = (float)tot;
+    double run = inner ? (double)((ci + 1e-5f) / sum) : 0.0;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const double v = __shfl_up(run, d);
+        if (lane >= d) run += v;
+    }
+    const float zn = __shfl_down(zi, 1);
+    if (lane <= nb) { cdf[lane] = lane == 0 ? 0.0f : (float)run; zmid[lane] = 0.5f * (zn + zi); }
+    zc[lane] = zi; // INFINITY beyond Sc
+    __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0): the wave's own LDS writes (no other wave touches this slice)
+    __builtin_amdgcn_wave_barrier();
+    float s = INFINITY;
+    if (lane < Sf) {
+        const float uk = u ? u[(size_t)r * Sf + lane] : t_lin[lane];
+        int lo = 0, hi = nb + 1; // searchsorted(cdf, uk, right=True): first position with cdf > uk
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (cdf[mid] <= uk) lo = mid + 1; else hi = mid;
+        }
+        const int ip = max(lo - 1, 0), in = min(lo, nb);
+        const float cp = cdf[ip], cn = cdf[in], zp = zmid[ip], zq = zmid[in];
+        float den = cn - cp;
+        if (den < 1e-5f) den = 1.0f;
+        s = zp + ((uk - cp) / den) * (zq - zp);
+        z_new[(size_t)r * Sf + lane] = s;
+        if (idx_out) idx_out[(size_t)r * Sf + lane] = in;
+    }
+    smp[lane] = s;
+    const float prev = __shfl_up(s, 1);
+    const bool unsorted = __ballot(lane >= 1 && lane < Sf && s < prev) != 0ull;
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    int rank = lane;
+    if (unsorted) { // stable rank: number of draws that sort before this one
+        rank = 0;
+        for (int jj = 0; jj < Sf; ++jj) {
+            const float o = smp[jj];
+            rank += (o < s || (o == s && jj < lane)) ? 1 : 0;
+        }
+    }
+    if (lane < Sf) { srt[rank] = s; perm[rank] = lane; }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    float* frow = z_fine + (size_t)r * (Sc + Sf);
+    int32_t* srow = src + (size_t)r * (Sc + Sf);
+    if (lane < Sc) { // coarse sample: position = lane + #(new < zi)
+        int lo = 0, hi = Sf;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (srt[mid] < zi) lo = mid + 1; else hi = mid; }
+        frow[lane + lo] = zi; srow[lane + lo] = lane;
+    }
+    if (lane < Sf) { // new sample (sorted order): position = lane + #(coarse <= value)
+        const float v = srt[lane];
+        int lo = 0, hi = Sc;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (zc[mid] <= v) lo = mid + 1; else hi = mid; }
+        frow[lane + lo] = v; srow[lane + lo] = ~perm[lane];
+    }
+}
+
 extern "C" int vanerf_importance_merge(const float* contrib, const float* z, const float* u, const float* t_lin, int R, int Sc, int Sf,
                                        float* z_new, float* z_fine, int32_t* src, int32_t* idx, void* stream)
 {
@@ -474,6 +562,12 @@ extern "C" int vanerf_importance_merge(const float* contrib, const float* z, con
         if (!contrib || !z || !z_new || !z_fine || !src) throw_error("vanerf_importance_merge: null argument");
         if (!u && !t_lin) throw_error("vanerf_importance_merge: need u (random) or t_lin (uniform)");
         if (R <= 0 || Sc < 3 || Sf < 1) throw_error("vanerf_importance_merge: R=%d Sc=%d Sf=%d", R, Sc, Sf);
+        if (Sc <= 64 && Sf <= 64) { // one wave per ray
+            hipLaunchKernelGGL(importance_merge_wave_kernel, dim3((R + IW_RAYS - 1) / IW_RAYS), dim3(64 * IW_RAYS), 0, (hipStream_t)stream, contrib, z, u,
+                               t_lin, R, Sc, Sf, z_new, z_fine, src, idx);
+            HIP_CHECK(hipGetLastError());
+            return;
+        }
         const size_t lds = (size_t)IM_BLOCK * sizeof(float) * (2 * (size_t)(Sc - 1) + 2 * (size_t)Sf);
         if (lds > 160 * 1024) throw_error("vanerf_importance_merge: %d + %d samples per ray exceed LDS", Sc, Sf);
         if (lds > 64 * 1024)
