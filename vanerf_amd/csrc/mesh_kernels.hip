@@ -388,18 +388,28 @@ __global__ __launch_bounds__(MA_BLOCK) void mesh_query_accel_kernel(const Vanerf
             const float gr = fmaxf(sqrtf(fmaxf(e2 * (1.0f - kappa) - h2 - tn.w, 0.0f)) - sp.w, 0.0f);
             return fmaxf(h2 - kappa * e2 - tn.w, 0.0f) + gr * gr;
         };
-        auto eval_t = [&](int t) { // the record comes through wave-uniform (scalar) loads: t is the same in every lane
-            const float4 sp = reinterpret_cast<const float4*>(A.sphere)[t];
-            const float4 tn = reinterpret_cast<const float4*>(A.tnorm)[t];
-            if (disc_lb2(sp, tn, p) > fminf(best, vb) * (1.0f + 1e-4f) + 1e-12f) return;
-            const float* q = A.tri + (size_t)t * 9;
-            const f3 a = {q[0], q[1], q[2]}, b = {q[3], q[4], q[5]}, c3 = {q[6], q[7], q[8]};
-            const float d = point_tri_dist2(p, a, b, c3);
+        // The records of a cluster come through wave-uniform (scalar) loads: the cluster index is the same in every lane.  All CL bound
+        // records are fetched before the first is used (one scalar-memory latency per cluster instead of one per triangle).
+        auto eval_cluster = [&](int c) {
+            float4 sp[CL], tn[CL];
+#pragma unroll
+            for (int k = 0; k < CL; ++k) {
+                sp[k] = reinterpret_cast<const float4*>(A.sphere)[c * CL + k];
+                tn[k] = reinterpret_cast<const float4*>(A.tnorm)[c * CL + k];
+            }
+#pragma unroll
+            for (int k = 0; k < CL; ++k) {
+                if (disc_lb2(sp[k], tn[k], p) > fminf(best, vb) * (1.0f + 1e-4f) + 1e-12f) continue;
+                const int t = c * CL + k;
+                const float* q = A.tri + (size_t)t * 9;
+                const f3 a = {q[0], q[1], q[2]}, b = {q[3], q[4], q[5]}, c3 = {q[6], q[7], q[8]};
+                const float d = point_tri_dist2(p, a, b, c3);
 #ifdef VANERF_MESH_PHASES
-            if (__builtin_ctzll(__ballot(1)) == lane) ph[7] += 1; // exact evaluations (some lane)
+                if (__builtin_ctzll(__ballot(1)) == lane) ph[7] += 1; // exact evaluations (some lane)
 #endif
-            const int of = A.orig[t];
-            if (d < best || (d == best && of < bf)) { best = d; bf = of; }
+                const int of = A.orig[t];
+                if (d < best || (d == best && of < bf)) { best = d; bf = of; }
+            }
         };
         // (1) seed: the cluster nearest to the centre of T, all of its triangles, so that every lane holds a bound close to its answer
         const f3 tc = {0.5f * (tlo[0] + thi[0]), 0.5f * (tlo[1] + thi[1]), 0.5f * (tlo[2] + thi[2])};
@@ -417,7 +427,7 @@ __global__ __launch_bounds__(MA_BLOCK) void mesh_query_accel_kernel(const Vanerf
                 if (o < smin || (o == smin && oc < cseed)) { smin = o; cseed = oc; }
             }
             cseed = __builtin_amdgcn_readfirstlane(cseed);
-            for (int k = 0; k < CL; ++k) eval_t(cseed * CL + k);
+            eval_cluster(cseed);
         }
         // (2) the other clusters: 64 at a time against T with the wave's largest bound, the survivors by every lane against its own
         const float capf = wave_max(fminf(best, vb)) * (1.0f + 1e-4f) + 1e-12f;
@@ -434,7 +444,7 @@ __global__ __launch_bounds__(MA_BLOCK) void mesh_query_accel_kernel(const Vanerf
 #ifdef VANERF_MESH_PHASES
                 if (__builtin_ctzll(__ballot(1)) == lane) ph[6] += 1; // ... whose triangles some lane looks at
 #endif
-                for (int k = 0; k < CL; ++k) eval_t(c * CL + k);
+                eval_cluster(c);
             }
         }
         MPH(2); // closest face
