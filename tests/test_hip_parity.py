@@ -201,6 +201,44 @@ def test_importance_merge_bit_exact_idx(R, golden):
     assert (zf2.cpu() - gi["merged"][0]).abs().max() <= (gi["z_mid"][0, :, -1] - gi["z_mid"][0, :, -2]).max()
 
 
+def test_importance_merge_unsorted_and_nonfinite_inputs(R):
+    """Whatever comes in, the origin map is a permutation (the composite gathers through it) and the merge is the sort of [z | draws]:
+    descending coarse depths (a camera whose far plane lies in front of the bounding box: near > far), NaN / inf contributions and depths."""
+    g = torch.Generator().manual_seed(7)
+    Rn, S = 600, 64
+    contrib = torch.rand(Rn, S, generator=g) ** 4
+    z = torch.sort(torch.rand(Rn, S, generator=g) * 0.3 + 0.8, -1)[0]
+    z[:200] = z[:200].flip(-1)                      # descending rows (near > far)
+    z[200:220] = z[200:220][:, torch.randperm(S, generator=g)]  # arbitrary order
+    contrib[300:310, 5] = float("nan")
+    contrib[310:320] = float("inf")
+    z[320:330, 7] = float("nan")
+    for kw in ({}, {"u": dev(torch.rand(Rn, S, generator=g))}):
+        z_new, z_fine, src = R.importance_merge(dev(contrib), dev(z), S, **kw)
+        col = torch.where(src.cpu().long() >= 0, src.cpu().long(), S + (-src.cpu().long() - 1))
+        assert torch.equal(torch.sort(col, -1)[0], torch.arange(2 * S).expand(Rn, -1))           # a permutation, always
+        both = torch.cat([z, z_new.cpu()], -1)
+        got = z_fine.cpu()
+        same = (torch.gather(both, 1, col) == got) | (torch.isnan(got) & torch.isnan(torch.gather(both, 1, col)))
+        assert same.all()
+        ok = torch.isfinite(both).all(-1)                                                         # rows without NaN / inf: the reference's sort
+        assert torch.equal(got[ok], torch.sort(both[ok], -1)[0])
+        assert ok[:220].all() and (got[:220, 1:] >= got[:220, :-1]).all()
+    # the mesh query on non-finite points: no out-of-range index (their answers are meaningless); finite points are unaffected
+    frame = _frame(3, 64)
+    verts = dev(frame["targets"]["vert_world"][0].contiguous())
+    faces = dev(frame["targets"]["face_world"][0].to(torch.int32))
+    p = dev(_points_near_mesh(frame, 256, seed=1))
+    p[::7] = float("nan")
+    p[3::11, 1] = float("inf")
+    vv = dev(torch.ones(verts.shape[0]))
+    s0, v0, f0 = R.mesh_query(verts, faces, vv, p, want_face=True)
+    s1, v1, f1, k1 = R.mesh_query_accel(R.MeshAccel(verts, faces), verts, faces, vv, p, want_face=True)
+    fin = torch.isfinite(p).all(-1)
+    assert torch.equal(f0[fin], f1[fin]) and torch.equal(v0[fin], v1[fin]) and torch.equal(s0[fin], s1[fin])
+    assert int(k1.min()) >= 0 and int(k1.max()) < verts.shape[0] and int(f1.min()) >= 0 and int(f1.max()) < faces.shape[0]  # in range, always
+
+
 def _query_both(R, sd, frame, pts, view=None):
     verts = frame["targets"]["vert_world"]
     xy01, z01 = orc.source_vert_xyz01(verts, frame["cam_in"])

@@ -133,3 +133,49 @@ def test_orbit_on_hip_path_matches_per_frame_render():
         want = (out["tex_fg_fine"].clamp(0, 1).permute(1, 2, 0) * 255.0).to(torch.uint8).cpu().numpy()
         assert np.array_equal(rgb[i], want)
     assert rgb.std() > 0 and not np.array_equal(rgb[0], rgb[2])
+
+
+@pytest.mark.gpu
+def test_render_video_on_hip_path(tmp_path):
+    """render_video with the real renderer: frames leave the GPU through the pinned side-stream copies of AsyncImageWriter and match the
+    frames render_novel_views returns."""
+    from PIL import Image
+    from vanerf_amd.config import default_config
+    from vanerf_amd.model import VANeRF
+    from vanerf_amd.novel_views import render_novel_views, render_video
+    torch.manual_seed(0)
+    cfg = default_config()
+    cfg["models"]["VANeRF"]["dr_kwargs"].update(sample_per_ray_c=8, sample_per_ray_f=8)
+    net = VANeRF(cfg).cuda().eval()
+    net.load_state_dict(synth.make_full_weights(0), strict=False)
+    frame = synth.to_device(synth.make_frame(seed=3, tar_h=256, tar_w=256), "cuda")
+    trb = synth.to_tr_batch(frame)
+    tar = frame["cam_tar"]
+    headpose = torch.inverse(tar["RT"][0])[:3, :4]
+    batch = dict(trb, index={"segment": ["seq"]}, human=torch.tensor([3]), headpose=headpose[None])
+    captured = {}
+
+    def decode(b):
+        return b
+
+    import vanerf_amd.novel_views as nv
+    orig = nv.get_360cameras
+
+    def cams(*a, **k):  # keep the orbit the driver built, to render the same cameras directly below
+        captured["cams"] = orig(*a, **k)
+        return captured["cams"]
+
+    nv.get_360cameras = cams
+    try:
+        written = render_video(net, [batch], str(tmp_path), decode_batch=decode, sc_factor=0.1, n_frames=3)
+    finally:
+        nv.get_360cameras = orig
+    assert len(written) == 3
+    rgb, _ = render_novel_views(net, captured["cams"], synth.to_tr_batch(frame), only_renderings=True)
+    for fi in range(3):
+        img = np.asarray(Image.open(tmp_path / "video" / "seq" / "3" / f"{fi:06d}.png"))
+        assert img.shape == (256, 512, 3)
+        # the encoders run again for the comparison render (MIOpen may pick another solver on a later call): allow the last uint8 step
+        diff = np.abs(img[:, 256:].astype(np.int16) - rgb[fi].astype(np.int16))
+        assert diff.max() <= 1 and (diff > 0).mean() < 1e-2
+    assert (tmp_path / "video" / "seq" / "3_nvs.gif").exists()

@@ -363,6 +363,7 @@ __global__ __launch_bounds__(MA_BLOCK) void mesh_query_accel_kernel(const Vanerf
                     eval_v(c);
                 }
             }
+            if (vi == 0x7fffffff) vi = 0; // a NaN point compares false with everything: index 0, like the exhaustive scan
             if (knn && act) knn[i] = vi;
         }
         MPH(1); // 1-NN
@@ -447,6 +448,7 @@ __global__ __launch_bounds__(MA_BLOCK) void mesh_query_accel_kernel(const Vanerf
                 eval_cluster(c);
             }
         }
+        if (bf == 0x7fffffff) bf = 0; // NaN point (see above): never index the face table with the sentinel
         MPH(2); // closest face
         // inside test on the (y,z) grid
         int cnt = 0;

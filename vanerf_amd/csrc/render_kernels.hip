@@ -525,35 +525,62 @@ __global__ __launch_bounds__(64 * IW_RAYS) void importance_merge_wave_kernel(con
         if (idx_out) idx_out[(size_t)r * Sf + lane] = in;
     }
     smp[lane] = s;
-    const float prev = __shfl_up(s, 1);
-    const bool unsorted = __ballot(lane >= 1 && lane < Sf && s < prev) != 0ull;
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    __builtin_amdgcn_wave_barrier();
-    int rank = lane;
-    if (unsorted) { // stable rank: number of draws that sort before this one
-        rank = 0;
-        for (int jj = 0; jj < Sf; ++jj) {
-            const float o = smp[jj];
-            rank += (o < s || (o == s && jj < lane)) ? 1 : 0;
-        }
-    }
-    if (lane < Sf) { srt[rank] = s; perm[rank] = lane; }
+    // Order: a total order on the bit patterns (key), so that the positions below always form a permutation of 0 .. Sc+Sf-1 whatever the
+    // values are -- a camera whose far plane lies in front of the bounding box yields DESCENDING coarse depths (near > far, the reference then
+    // sorts everything: th.sort(th.cat([z, z_fine])), src/model.py:1303), and a NaN anywhere must not leave a slot of `src` unwritten (the
+    // composite gathers through it).  key(a) < key(b) <=> a < b for ordinary floats; NaNs sort last.
+    auto key = [](float f) { const unsigned b = __float_as_uint(f); return b ^ ((b >> 31) ? 0xffffffffu : 0x80000000u); };
+    const unsigned ks = key(s), kz = key(zi);
+    const unsigned kprev = __shfl_up(ks, 1), kzprev = __shfl_up(kz, 1);
+    const bool new_unsorted = __ballot(lane >= 1 && lane < Sf && ks < kprev) != 0ull;
+    const bool coarse_unsorted = __ballot(lane >= 1 && lane < Sc && kz < kzprev) != 0ull;
+    unsigned* kn = reinterpret_cast<unsigned*>(smp);  // keys of the draws, draw order
+    unsigned* kc = reinterpret_cast<unsigned*>(zc);   // keys of the coarse depths
+    unsigned* ksrt = reinterpret_cast<unsigned*>(srt); // keys of the draws, sorted
+    kn[lane] = ks;
+    kc[lane] = kz;
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
     float* frow = z_fine + (size_t)r * (Sc + Sf);
     int32_t* srow = src + (size_t)r * (Sc + Sf);
-    if (lane < Sc) { // coarse sample: position = lane + #(new < zi)
-        int lo = 0, hi = Sf;
-        while (lo < hi) { const int mid = (lo + hi) >> 1; if (srt[mid] < zi) lo = mid + 1; else hi = mid; }
-        frow[lane + lo] = zi; srow[lane + lo] = lane;
-    }
-    if (lane < Sf) { // new sample (sorted order): position = lane + #(coarse <= value)
-        const float v = srt[lane];
-        int lo = 0, hi = Sc;
-        while (lo < hi) { const int mid = (lo + hi) >> 1; if (zc[mid] <= v) lo = mid + 1; else hi = mid; }
-        frow[lane + lo] = v; srow[lane + lo] = ~perm[lane];
+    if (!coarse_unsorted) {
+        int rank = lane;
+        if (new_unsorted) { // stable rank of this draw among the draws (the insertion sort of the serial kernel)
+            rank = 0;
+            for (int jj = 0; jj < Sf; ++jj) { const unsigned o = kn[jj]; rank += (o < ks || (o == ks && jj < lane)) ? 1 : 0; }
+        }
+        if (lane < Sf) { ksrt[rank] = ks; perm[rank] = lane; }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        if (lane < Sc) { // coarse sample: position = lane + #(draws < it)
+            int lo = 0, hi = Sf;
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (ksrt[mid] < kz) lo = mid + 1; else hi = mid; }
+            frow[lane + lo] = zi; srow[lane + lo] = lane;
+        }
+        if (lane < Sf) { // draw `lane` of the sorted order: position = lane + #(coarse <= it)
+            const unsigned v = ksrt[lane];
+            const int pl = perm[lane];
+            int lo = 0, hi = Sc;
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (kc[mid] <= v) lo = mid + 1; else hi = mid; }
+            frow[lane + lo] = __shfl(s, pl); srow[lane + lo] = ~pl;
+        }
+    } else { // coarse depths not ascending: full stable sort of [coarse | draws] by counting
+        int pc = 0, pn = 0;
+        for (int jj = 0; jj < Sc; ++jj) {
+            const unsigned o = kc[jj];
+            pc += (o < kz || (o == kz && jj < lane)) ? 1 : 0; // coarse before coarse
+            pn += (o <= ks) ? 1 : 0;                           // coarse before a draw (coarse first on ties)
+        }
+        for (int jj = 0; jj < Sf; ++jj) {
+            const unsigned o = kn[jj];
+            pc += (o < kz) ? 1 : 0;
+            pn += (o < ks || (o == ks && jj < lane)) ? 1 : 0;
+        }
+        if (lane < Sc) { frow[pc] = zi; srow[pc] = lane; }
+        if (lane < Sf) { frow[pn] = s; srow[pn] = ~lane; }
     }
 }
+
 
 extern "C" int vanerf_importance_merge(const float* contrib, const float* z, const float* u, const float* t_lin, int R, int Sc, int Sf,
                                        float* z_new, float* z_fine, int32_t* src, int32_t* idx, void* stream)
