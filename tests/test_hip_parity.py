@@ -239,6 +239,27 @@ def test_importance_merge_unsorted_and_nonfinite_inputs(R):
     assert int(k1.min()) >= 0 and int(k1.max()) < verts.shape[0] and int(f1.min()) >= 0 and int(f1.max()) < faces.shape[0]  # in range, always
 
 
+@pytest.mark.parametrize("S", [16, 72])  # 72 + 72 samples take the one-thread-per-ray importance kernel
+def test_far_plane_in_front_of_the_bbox(R, sd_full, S):
+    """near > far on the rays that hit the bounding box (zfar closer than the box): coarse depths descend, the reference sorts the merged
+    depths (src/model.py:1303).  Whole pass against the oracle."""
+    frame = _frame(3, 64)
+    frame["cam_tar"] = dict(frame["cam_tar"], znear=0.3, zfar=0.85)
+    fdat = _frame_data(R, sd_full, frame)
+    w = R.PackedWeights(sd_full)
+    out = R.render_pass(w, fdat, frame["cam_tar"], frame["bounds"], 1, 2, 4, 16, 16, S, S)
+    assert (out["z"][out["hit"].bool()][:, 1:] <= out["z"][out["hit"].bool()][:, :-1]).all() and out["hit"].float().mean() > 0.2
+    zf = out["z_fine"]
+    assert (zf[:, 1:] >= zf[:, :-1]).all()
+    ref = orc.batch_render(sd_full, frame, 3, torch.tensor([[[1, 2]]]), S, S)
+    assert torch.equal(out["index"].cpu(), ref["index"][0])
+    for k, rk in (("color", "tex_fg"), ("color_fine", "tex_fg_fine")):
+        got = out[k].cpu().view(16, 16, 3).permute(2, 0, 1)
+        assert torch.isfinite(got).all() == torch.isfinite(ref[rk][0]).all()
+        fin = torch.isfinite(ref[rk][0]) & torch.isfinite(got)
+        assert_close_frac(got[fin], ref[rk][0][fin], TOL, 2 * OUTLIERS, rk)
+
+
 def _query_both(R, sd, frame, pts, view=None):
     verts = frame["targets"]["vert_world"]
     xy01, z01 = orc.source_vert_xyz01(verts, frame["cam_in"])

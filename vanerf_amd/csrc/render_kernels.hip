@@ -274,12 +274,27 @@ __global__ __launch_bounds__(IM_BLOCK) void importance_merge_kernel(const float*
         }
     }
     int a = 0, b = 0;
+    bool asc = true;
+    float last = -INFINITY;
     for (int k = 0; k < Sc + Sf; ++k) {
         const float za = a < Sc ? zr[a] : INFINITY;
         const float zb = b < Sf ? smp[(size_t)b * IM_BLOCK] : INFINITY;
         const bool take_a = (a < Sc) && (b >= Sf || za <= zb);
-        if (take_a) { frow[k] = za; srow[k] = a; ++a; }
-        else { frow[k] = zb; srow[k] = ~perm[(size_t)b * IM_BLOCK]; ++b; }
+        float v;
+        if (take_a) { v = za; frow[k] = za; srow[k] = a; ++a; }
+        else { v = zb; frow[k] = zb; srow[k] = ~perm[(size_t)b * IM_BLOCK]; ++b; }
+        asc = asc && (v >= last);
+        last = v;
+    }
+    if (!asc) { // the coarse depths were not ascending (near > far: a far plane in front of the bounding box): the reference sorts the
+                // concatenation (src/model.py:1303) -- stable insertion sort of the merged row, values and origins together
+        for (int k = 1; k < Sc + Sf; ++k) {
+            const float v = frow[k];
+            const int32_t o = srow[k];
+            int m = k - 1;
+            while (m >= 0 && frow[m] > v) { frow[m + 1] = frow[m]; srow[m + 1] = srow[m]; --m; }
+            frow[m + 1] = v; srow[m + 1] = o;
+        }
     }
 }
 
