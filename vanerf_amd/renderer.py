@@ -270,6 +270,8 @@ class FrameData:
         verts = targets["vert_world"].to(dev, f32)
         faces = targets["face_world"].to(dev).long()
         assert verts.shape == (1, NV, 3), verts.shape
+        if faces.numel() == 0 or int(faces.min()) < 0 or int(faces.max()) >= NV:  # the mesh kernels index the vertex table with these
+            raise ValueError("face_world holds vertex indices outside [0, 1558)")
         W, H = float(cam_in["width"]), float(cam_in["height"])
         znear, zfar = float(cam_in["znear"]), float(cam_in["zfar"])
         # vertices in the source view (src/model.py:845-853 for sampling, 1245-1255 for the visibility raster)
