@@ -288,7 +288,7 @@ class VANeRF(nn.Module):
         uniform = config.get("uniform", False)
         if config.get("separate_cf", False):
             raise NotImplementedError("separate_cf is not used by the shipped configs")
-        noise_std = config.get("rand_noise_std", 0.0) if net.training else config.get("rand_noise_std", 0.0)
+        noise_std = config.get("rand_noise_std", 0.0)  # applied whenever the caller passes it, train or eval (src/model.py:1128, 1155)
         if feat_geo is None:
             feat_geo = net.attach_geo_feat(img_in, return_val=True)
         if feat_tex is None:
