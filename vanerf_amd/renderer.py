@@ -6,8 +6,7 @@ TexVisFusion per-frame conv stack).  Every per-ray / per-sample operation runs i
 There is no CPU or eager fallback: every entry point requires CUDA(ROCm) tensors.
 """
 import ctypes
-import math
-from ctypes import POINTER, byref, c_float, c_int64, c_uint, c_void_p
+from ctypes import byref, c_float, c_int64, c_uint, c_void_p
 
 import torch
 import torch.nn.functional as F
