@@ -1,0 +1,33 @@
+"""Time of one training step of the drop-in module on one GPU: HIP forward of the 64x64 patch (values) + PyTorch graph at the same samples
+(gradients) + backward (BASELINE config 5, first stage of SURVEY.md section 8 row f-4)."""
+import os, sys, time, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from vanerf_amd import synth
+from vanerf_amd.config import default_config
+from vanerf_amd.model import VANeRF
+torch.manual_seed(0)
+net = VANeRF(default_config()).cuda().train()
+net.load_state_dict(synth.make_full_weights(0), strict=False)
+frame = synth.to_device(synth.make_frame(seed=3, tar_h=256, tar_w=256), "cuda")
+dr = {"img": frame["img_in"], "cam": frame["cam_in"], "cam_tar": frame["cam_tar"], "tar": torch.rand(1, 3, 256, 256, device="cuda"),
+      "msk": torch.ones(1, 1, 256, 256, device="cuda")}
+opt = torch.optim.Adam(net.parameters(), lr=1e-5)
+def step():
+    out = net(frame["img_in"], frame["cam_in"], frame["hand_type"], frame["targets"], None, None, n_views=1, sp_data=dict(frame["sp_data"]),
+              dr_data=dr, src_foreground_mask=frame["src_foreground_mask"], bounds=frame["bounds"])["out"]["nerf"]
+    loss = (out["tex_fg_fine"] - out["tar_img"]).abs().mean() + (out["tex_fg"] - out["tar_img"]).abs().mean() + 0.1 * out["alpha_fine"].mean()
+    opt.zero_grad(set_to_none=True)
+    loss.backward()
+    opt.step()
+    return float(loss.detach())
+for _ in range(2):
+    step()
+torch.cuda.synchronize()
+ts = []
+for _ in range(5):
+    t0 = time.perf_counter(); l = step(); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+with torch.no_grad():
+    net.eval(); torch.cuda.synchronize(); t0 = time.perf_counter()
+    net.train()
+print(f"training step (64x64 patch, 64+64 samples, encoders + HIP forward + torch graph + backward + Adam): min {1e3 * min(ts):.1f} ms, loss {l:.4f}, "
+      f"peak memory {torch.cuda.max_memory_allocated() / 2**30:.2f} GiB")
