@@ -167,15 +167,17 @@ __device__ __forceinline__ void run_layer(f32x16 (&acc)[NB], Ring<NB>& ring, WRs
 // k-pairs of the fp32 ordering, so the accumulator -> operand chaining of layer_spec.h is unchanged.  Measured against the fp32
 // oracle the dropped W_lo X_lo term and the 16-bit operands cost 1.2e-5 absolute on the outputs (the fp32-MFMA path: 9e-6).
 // ---------------------------------------------------------------------------------------------
-// ring depths (steps in flight) for layers with 4/3, 1 and 2 output blocks; measured 8.54 / 8.56 / 8.65 ms for (3,6,3) / (4,4,4) / (2,4,2)
+// ring depths (steps in flight) for layers with 4/3, 1 and 2 output blocks.  With the pinned software pipeline of run_layer_b, measured in
+// one session: (2,4,2) 8.16-8.23 ms, (2,3,2) 8.22, (2,2,2) 8.24, (1,4,2) 8.25, (3,6,3) 8.32, (1,2,1) 8.33, (4,8,4) +4 %, (5,8,4) +8 %:
+// two k-steps ahead cover the L2 latency, deeper rings only add loads in flight
 #ifndef VANERF_RINGB_WIDE
-#define VANERF_RINGB_WIDE 3
+#define VANERF_RINGB_WIDE 2
 #endif
 #ifndef VANERF_RINGB_D1
-#define VANERF_RINGB_D1 6
+#define VANERF_RINGB_D1 4
 #endif
 #ifndef VANERF_RINGB_D2
-#define VANERF_RINGB_D2 3
+#define VANERF_RINGB_D2 2
 #endif
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
