@@ -260,6 +260,37 @@ def test_far_plane_in_front_of_the_bbox(R, sd_full, S):
         assert_close_frac(got[fin], ref[rk][0][fin], TOL, 2 * OUTLIERS, rk)
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_arbitrary_target_cameras_are_safe(R, sd_full, precision):
+    """Cameras a caller may hand in: behind the hand, inside its bounding box, far plane in front of the box, near == far, a view that
+    misses the box entirely.  Every launch must stay in bounds (the merged depths are sorted, the origin map is a permutation) and give
+    finite images whenever the depth range is not degenerate."""
+    base = _frame(3, 64)
+    fdat = _frame_data(R, sd_full, base)
+    w = R.PackedWeights(sd_full, mode=precision)
+    centre = base["targets"]["vert_world"][0].mean(0)
+    g = torch.Generator().manual_seed(11)
+    cams = []
+    for k in range(10):
+        d = torch.randn(3, generator=g)
+        eye = centre + torch.nn.functional.normalize(d, dim=0) * float(0.02 + torch.rand(1, generator=g) * 1.5)  # inside the box .. 1.5 away
+        look = centre + (0.01 if k % 3 else 0.3) * torch.randn(3, generator=g)                                    # some look past the hand
+        E = torch.from_numpy(synth.look_at_extrinsic(eye.numpy(), look.numpy()))
+        K = base["cam_tar"]["K"][0].clone()
+        K[0, 0] = K[1, 1] = float(200 + 3000 * torch.rand(1, generator=g))
+        zn = float(torch.rand(1, generator=g) * 0.8 + 0.01)
+        zf = zn if k == 4 else zn + float(torch.rand(1, generator=g) * (0.2 if k % 2 else 2.0))
+        cams.append(dict(base["cam_tar"], K=K[None], RT=E[None], KRT=(K @ E)[None], znear=zn, zfar=zf))
+    for k, cam in enumerate(cams):
+        out = R.render_pass(w, fdat, cam, base["bounds"], 0, 0, 4, 16, 16, 16, 16)
+        torch.cuda.synchronize()
+        zf_ = out["z_fine"]
+        assert zf_.shape == (256, 32) and ((zf_[:, 1:] >= zf_[:, :-1]) | torch.isnan(zf_[:, 1:]) | torch.isnan(zf_[:, :-1])).all(), k
+        if k != 4:
+            assert torch.isfinite(out["color_fine"]).all() and torch.isfinite(out["depth_fine"]).all(), k
+            assert (out["alpha_fine"] >= 0).all() and (out["alpha_fine"] <= 1.0 + 1e-5).all(), k
+
+
 def _query_both(R, sd, frame, pts, view=None):
     verts = frame["targets"]["vert_world"]
     xy01, z01 = orc.source_vert_xyz01(verts, frame["cam_in"])
