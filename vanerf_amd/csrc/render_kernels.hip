@@ -78,8 +78,9 @@ __global__ void ray_bbox_kernel(const BboxParams B, const float* __restrict__ di
     near[r] = z1; far[r] = z2; hit[r] = h;
 }
 
-__global__ void ray_setup_kernel(const RayParams P)
+__global__ __launch_bounds__(256) void ray_setup_kernel(const RayParams P)
 {
+    __shared__ float s_near[256], s_far[256];
     const int R = P.nx * P.ny;
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     // camera centre: -(t . R)  (src/model.py:1213)
@@ -89,7 +90,8 @@ __global__ void ray_setup_kernel(const RayParams P)
     const float oy = -((tx * M[1] + ty * M[5]) + tz * M[9]);
     const float oz = -((tx * M[2] + ty * M[6]) + tz * M[10]);
     if (r == 0) { P.cam_pos[0] = ox; P.cam_pos[1] = oy; P.cam_pos[2] = oz; }
-    if (r >= R) return;
+    float near = 0.0f, far = 0.0f;
+    if (r < R) {
     const int ix = r % P.nx, iy = r / P.nx;
     const int gxi = P.pixels ? P.pixels[2 * r] : P.x0 + ix * P.step_x;
     const int gyi = P.pixels ? P.pixels[2 * r + 1] : P.y0 + (iy / P.y_block) * P.step_y + (iy % P.y_block) * P.step_x;
@@ -114,20 +116,24 @@ __global__ void ray_setup_kernel(const RayParams P)
 
     float z1, z2;
     const bool hit = ray_bbox(P.bounds, ox, oy, oz, dx, dy, dz, z1, z2);
-    const float near = (hit && z1 > zn) ? z1 : zn; // src/model.py:1217-1220
-    const float far = (hit && z2 < zf) ? z2 : zf;
+    near = (hit && z1 > zn) ? z1 : zn; // src/model.py:1217-1220
+    far = (hit && z2 < zf) ? z2 : zf;
     P.near[r] = near; P.far[r] = far; P.hit[r] = hit;
-
-    // coarse depths (src/model.py:1222-1232)
+    }
+    // coarse depths (src/model.py:1222-1232), written by the whole block in memory order (a thread per ray wrote 64 cache lines per store)
+    s_near[threadIdx.x] = near; s_far[threadIdx.x] = far;
+    __syncthreads();
     const int S = P.S;
-    for (int i = 0; i < S; ++i) {
+    const int r0 = blockIdx.x * blockDim.x, nr = min((int)blockDim.x, R - r0);
+    for (int k = threadIdx.x; k < nr * S; k += blockDim.x) {
+        const int rl = k / S, i = k - rl * S;
         float t = P.t_lin[i];
         if (P.jitter) {
             float lo_t = i == 0 ? P.t_lin[0] : 0.5f * (P.t_lin[i] + P.t_lin[i - 1]);
             float hi_t = i == S - 1 ? P.t_lin[S - 1] : 0.5f * (P.t_lin[i + 1] + P.t_lin[i]);
-            t = lo_t + P.jitter[(size_t)r * S + i] * (hi_t - lo_t);
+            t = lo_t + P.jitter[(size_t)(r0 + rl) * S + i] * (hi_t - lo_t);
         }
-        P.z[(size_t)r * S + i] = near + (far - near) * t;
+        P.z[(size_t)(r0 + rl) * S + i] = s_near[rl] + (s_far[rl] - s_near[rl]) * t;
     }
 }
 
