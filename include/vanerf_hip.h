@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define VANERF_ABI_VERSION 3
+#define VANERF_ABI_VERSION 4
 
 #define VANERF_OK 0
 #define VANERF_EINVAL (-22)
@@ -178,11 +178,21 @@ int vanerf_knn1(const float* verts4, int nv, const float* pts, int64_t n, int32_
 /* a7-a15  VANeRF.query + eval_func for N samples (src/model.py:748-957, 1140-1160), n_views = 1:
  *     pts[N][3], query_sdf[N], query_vis[N] (u8), knn_idx[N] (1-NN vertex, from vanerf_mesh_query_accel or vanerf_knn1),
  *     noise[N] or NULL (rand_noise_std draws, model.py:1156)
+ *     order[N] or NULL: a permutation of 0..N-1 from vanerf_query_order; slot k of the launch then works on sample order[k].  Inputs are
+ *         read and outputs written at the sample's own index either way: the results do not depend on `order`, only the time does.
  *     raw = 0 -> out[N][5] = [alpha, sdf, r, g, b] (eval_func applied);  raw = 1 -> [sdf_pred, rad, r, g, b] as VANeRF.query returns
  *     valid[N] (u8, may be NULL)                                                                                          */
 int vanerf_query_samples(const VanerfWeights* w, const VanerfFrame* frame, const float* pts, const float* query_sdf,
-                         const uint8_t* query_vis, const int32_t* knn_idx, const float* noise, int raw, int64_t n, float* out,
-                         uint8_t* valid, void* stream);
+                         const uint8_t* query_vis, const int32_t* knn_idx, const float* noise, const int32_t* order, int raw, int64_t n,
+                         float* out, uint8_t* valid, void* stream);
+
+/* Validity partition for vanerf_query_samples: order[N] = the samples whose projection hits the source view and its foreground mask
+ * (src/model.py:780-803), in their order, then the others, in their order.  A 32-sample group of vanerf_query_samples in which no sample
+ * is valid skips the geometry networks; with this order only one group per launch is mixed.  scratch: device memory of at least
+ * vanerf_query_order_scratch(n) bytes.                                                                                          */
+int vanerf_query_order(const VanerfFrame* frame, const float* pts, int64_t n, int32_t* order, void* scratch, int64_t scratch_bytes,
+                       void* stream);
+int64_t vanerf_query_order_scratch(int64_t n);
 
 /* a16  sdf_activation + rgba2out (src/model.py:879-882, 1464-1494):
  *     rgba[R][S][5], z[R][S], mesh_sdf[R][S] -> color[R][3], depth[R], alpha[R], sdf[R], contrib[R][S] (may be NULL)      */

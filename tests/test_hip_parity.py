@@ -361,6 +361,32 @@ def test_split_bf16_matches_fp32_kernel_full_size(R, sd_full):
     assert err.max() <= TOL
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_validity_partition_changes_nothing_but_the_order_of_work(R, sd_full, precision):
+    """vanerf_query_order: a permutation, valid samples first in their order, then the others in theirs; vanerf_query_samples gives the
+    same bits with and without it (half-masked source view, so that many groups are mixed; ragged sizes)."""
+    frame = _frame(5, 128, 40.0, True)
+    fdat = _frame_data(R, sd_full, frame)
+    w = R.PackedWeights(sd_full, mode=precision)
+    rays = R.ray_setup(frame["cam_tar"], frame["bounds"], 0, 0, 1, 128, 128, 24, device="cuda")
+    pts_all = R.sample_points(rays["rays_d"], rays["cam_pos"], rays["z"])
+    for n in (pts_all.shape[0], 1000 * 24 + 7, 33, 1):
+        pts = pts_all[:n].contiguous()
+        q_sdf, q_vis, knn = R.mesh_query_accel(fdat.accel, fdat.verts3, fdat.faces, fdat.vert_vis, pts)
+        ref, valid = R.query_samples(w, fdat, pts, q_sdf, q_vis, knn, want_valid=True)
+        order = R.query_order(fdat, pts)
+        o = order.long().cpu()
+        assert torch.equal(torch.sort(o)[0], torch.arange(n))
+        v = valid.bool().cpu()
+        nv = int(v.sum())
+        assert v[o[:nv]].all() and not v[o[nv:]].any()
+        assert (o[:nv][1:] > o[:nv][:-1]).all() and (o[nv:][1:] > o[nv:][:-1]).all()      # stable
+        got, valid2 = R.query_samples(w, fdat, pts, q_sdf, q_vis, knn, want_valid=True, order=order)
+        assert torch.equal(got, ref) and torch.equal(valid2, valid)
+        if n > 10000:
+            assert 0.05 < v.float().mean() < 0.95
+
+
 def test_query_samples_vs_reference_golden(R, sd_full, golden):
     """Golden vector produced by the reference's own VANeRF.query (tests/golden/query.npz)."""
     g = golden("query")

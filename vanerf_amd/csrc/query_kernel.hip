@@ -65,6 +65,7 @@ struct QueryParams {
     const uint8_t* qvis;
     const float* noise;
     const int32_t* knn_in;
+    const int32_t* order;  // optional: slot k of the launch works on sample order[k] (validity partition), else on sample k
     int raw; // 1: write [sdf_pred, rad, r, g, b] (VANeRF.query), 0: eval_func applied ([alpha, sdf, r, g, b])
     long long n;
     float* out;
@@ -415,6 +416,27 @@ template <int C4> __device__ __forceinline__ void load_row(const float* __restri
     }
 }
 
+// Projection of a sample into the source view and its validity mask (src/model.py:780-803).  ONE definition, used by query_kernel
+// and by the validity partition below, so that both always take the same decision.
+struct Projected { float x, y, zn, mask; };
+__device__ __forceinline__ Projected project_and_mask(const VanerfFrame& F, float wm1, float hm1, float px, float py, float pz)
+{
+    const float vx = fmaf(pz, F.KRT[2], fmaf(py, F.KRT[1], px * F.KRT[0])) + F.KRT[3];
+    const float vy = fmaf(pz, F.KRT[6], fmaf(py, F.KRT[5], px * F.KRT[4])) + F.KRT[7];
+    const float vz = fmaf(pz, F.KRT[10], fmaf(py, F.KRT[9], px * F.KRT[8])) + F.KRT[11];
+    Projected r;
+    r.x = 2.0f * ((vx / vz) / (F.width - 1.0f)) - 1.0f;
+    r.y = 2.0f * ((vy / vz) / (F.height - 1.0f)) - 1.0f;
+    r.zn = 2.0f * (vz - F.znear) / (F.zfar - F.znear) - 1.0f;
+    const float eps = 1e-2f;
+    const bool in_img = (r.x >= -1.0f - eps) && (r.x <= 1.0f + eps) && (r.y >= -1.0f - eps) && (r.y <= 1.0f + eps) && (r.zn >= -1.0f);
+    const Bilin bi = bilin_setup(r.x, r.y, F.hi, F.wi, wm1, hm1);
+    const float fg = bilin_mix(bi, ld_off<float>(F.mask, 4u * bi.o00), ld_off<float>(F.mask, 4u * bi.o01), ld_off<float>(F.mask, 4u * bi.o10),
+                               ld_off<float>(F.mask, 4u * bi.o11));
+    r.mask = (in_img && fg > 0.1f) ? 1.0f : 0.0f;
+    return r;
+}
+
 // one GeoVisFusion scale (src/networks.py:83-94 / 96-104): gates, gated 2-layer MLP.
 //   HC = channels per lane half (32 for the 64-channel map, 4 for the 8-channel map), NBO = output blocks,
 //   NREG_MID = registers of the last hidden block that carry real channels
@@ -498,7 +520,8 @@ __global__ __launch_bounds__(BLOCK, MODE == 1 ? VANERF_WAVES_PER_SIMD_B : VANERF
     struct SampleIn { float px, py, pz, sdf; int knn; unsigned char vis; };
     auto fetch = [&](unsigned grp) {
         const long long sr = (long long)grp * 32 + j;
-        const long long sc = sr < P.n ? sr : P.n - 1; // also covers a claim beyond the last group (never used)
+        long long sc = sr < P.n ? sr : P.n - 1; // also covers a claim beyond the last group (never used)
+        if (P.order) sc = P.order[sc];
         SampleIn in;
         in.px = P.pts[3 * sc]; in.py = P.pts[3 * sc + 1]; in.pz = P.pts[3 * sc + 2];
         in.sdf = P.qsdf[sc]; in.knn = P.knn_in[sc]; in.vis = P.qvis[sc];
@@ -514,24 +537,16 @@ __global__ __launch_bounds__(BLOCK, MODE == 1 ? VANERF_WAVES_PER_SIMD_B : VANERF
         __builtin_amdgcn_sched_barrier(0x000F); // keep these loads here (the scheduler sinks loads to their first use)
         const long long s_raw = g * 32 + j;
         const bool live = s_raw < P.n;
-        const long long s = live ? s_raw : P.n - 1;
+        long long s = live ? s_raw : P.n - 1;
+        if (P.order) s = P.order[s];
         const float px = in.px, py = in.py, pz = in.pz;
         const float q_sdf = in.sdf;
         const float q_vis = in.vis ? 1.0f : 0.0f;
 
         // ---- projection into the source view, validity mask, boundary weight (src/model.py:780-821) ----
-        float vx = fmaf(pz, F.KRT[2], fmaf(py, F.KRT[1], px * F.KRT[0])) + F.KRT[3];
-        float vy = fmaf(pz, F.KRT[6], fmaf(py, F.KRT[5], px * F.KRT[4])) + F.KRT[7];
-        float vz = fmaf(pz, F.KRT[10], fmaf(py, F.KRT[9], px * F.KRT[8])) + F.KRT[11];
-        float x = 2.0f * ((vx / vz) / (F.width - 1.0f)) - 1.0f;
-        float y = 2.0f * ((vy / vz) / (F.height - 1.0f)) - 1.0f;
-        float zn = 2.0f * (vz - F.znear) / (F.zfar - F.znear) - 1.0f;
-        const float eps = 1e-2f;
-        bool in_img = (x >= -1.0f - eps) && (x <= 1.0f + eps) && (y >= -1.0f - eps) && (y <= 1.0f + eps) && (zn >= -1.0f);
-        const Bilin bi = bilin_setup(x, y, F.hi, F.wi, P.wm1[0], P.hm1[0]);
-        float fg = bilin_mix(bi, ld_off<float>(F.mask, 4u * bi.o00), ld_off<float>(F.mask, 4u * bi.o01), ld_off<float>(F.mask, 4u * bi.o10),
-                              ld_off<float>(F.mask, 4u * bi.o11));
-        const float mask = (in_img && fg > 0.1f) ? 1.0f : 0.0f;
+        const Projected pr = project_and_mask(F, P.wm1[0], P.hm1[0], px, py, pz);
+        const float x = pr.x, y = pr.y, zn = pr.zn, mask = pr.mask;
+        const Bilin bi = bilin_setup(x, y, F.hi, F.wi, P.wm1[0], P.hm1[0]); // source-image taps (the same the mask used)
         float pw;
         {
             float ux = 0.5f * x + 0.5f, uy = 0.5f * y + 0.5f, uz = 0.5f * zn + 0.5f;
@@ -833,8 +848,8 @@ __global__ __launch_bounds__(BLOCK, MODE == 1 ? VANERF_WAVES_PER_SIMD_B : VANERF
 } // namespace
 
 extern "C" int vanerf_query_samples(const VanerfWeights* w, const VanerfFrame* frame, const float* pts, const float* query_sdf,
-                                    const uint8_t* query_vis, const int32_t* knn_idx, const float* noise, int raw, int64_t n, float* out,
-                                    uint8_t* valid, void* stream)
+                                    const uint8_t* query_vis, const int32_t* knn_idx, const float* noise, const int32_t* order, int raw, int64_t n,
+                                    float* out, uint8_t* valid, void* stream)
 {
     return guarded([&] {
         if (n < 0) throw_error("vanerf_query_samples: n = %lld < 0", (long long)n);
@@ -847,7 +862,7 @@ extern "C" int vanerf_query_samples(const VanerfWeights* w, const VanerfFrame* f
         if (f.h0 < 1 || f.w0 < 1 || f.h1 < 1 || f.w1 < 1 || f.ht < 1 || f.wt < 1 || f.hi < 1 || f.wi < 1)
             throw_error("vanerf_query_samples: feature-map sizes must be positive");
         QueryParams P;
-        P.f = f; P.w = w->dev; P.wbytes = (unsigned)(w->n_floats * sizeof(float)); P.pts = pts; P.qsdf = query_sdf; P.qvis = query_vis; P.noise = noise; P.knn_in = knn_idx; P.raw = raw;
+        P.f = f; P.w = w->dev; P.wbytes = (unsigned)(w->n_floats * sizeof(float)); P.pts = pts; P.qsdf = query_sdf; P.qvis = query_vis; P.noise = noise; P.knn_in = knn_idx; P.order = order; P.raw = raw;
         P.n = n; P.out = out; P.valid = valid; P.stamps = nullptr; P.short_groups = w->stats;
         { const int ws[4] = {P.f.wi, P.f.wt, P.f.w0, P.f.w1}, hs[4] = {P.f.hi, P.f.ht, P.f.h0, P.f.h1};
           for (int i = 0; i < 4; ++i) { P.wm1[i] = (float)(ws[i] - 1); P.hm1[i] = (float)(hs[i] - 1); } }
@@ -873,6 +888,98 @@ extern "C" int vanerf_query_samples(const VanerfWeights* w, const VanerfFrame* f
     });
 }
 
+// ---------------------------------------------------------------------------------------------
+// Validity partition.  A 32-sample group whose samples ALL miss the source view takes the short path of query_kernel; groups are
+// consecutive samples of a ray, and on the benchmark view 12.5 % of them are mixed: their invalid samples (7 % of all samples) ride
+// through the long path.  vanerf_query_order computes the validity of every sample with the kernel's own project_and_mask and writes the
+// stable partition [valid samples in order | invalid samples in order]; query_kernel then works on slot k = sample order[k], so only one
+// group per launch is mixed.  Results are the same bits (the networks are per-sample functions; outputs are stored at the sample's place).
+// Three small kernels: flags + per-block counts, scan of the block counts, scatter.
+// ---------------------------------------------------------------------------------------------
+constexpr int CP_BLOCK = 1024;
+
+__global__ __launch_bounds__(CP_BLOCK) void order_count_kernel(const VanerfFrame F, float wm1, float hm1, const float* __restrict__ pts, long long n,
+                                                               uint8_t* __restrict__ flags, unsigned* __restrict__ block_valid)
+{
+    const long long s = (long long)blockIdx.x * CP_BLOCK + threadIdx.x;
+    int valid = 0;
+    if (s < n) {
+        valid = project_and_mask(F, wm1, hm1, pts[3 * s], pts[3 * s + 1], pts[3 * s + 2]).mask > 0.0f;
+        flags[s] = (uint8_t)valid;
+    }
+    const int cnt = __syncthreads_count(valid);
+    if (threadIdx.x == 0) block_valid[blockIdx.x] = (unsigned)cnt;
+}
+
+// exclusive scan of block_valid[nblocks] in place; total -> block_valid[nblocks]
+__global__ __launch_bounds__(CP_BLOCK) void order_scan_kernel(unsigned* __restrict__ block_valid, int nblocks)
+{
+    __shared__ unsigned s_sum[CP_BLOCK];
+    const int per = (nblocks + CP_BLOCK - 1) / CP_BLOCK;
+    const int b0 = threadIdx.x * per, b1 = min(b0 + per, nblocks);
+    unsigned loc = 0;
+    for (int b = b0; b < b1; ++b) loc += block_valid[b];
+    s_sum[threadIdx.x] = loc;
+    __syncthreads();
+    for (int d = 1; d < CP_BLOCK; d <<= 1) { // Hillis-Steele inclusive scan
+        const unsigned v = threadIdx.x >= (unsigned)d ? s_sum[threadIdx.x - d] : 0u;
+        __syncthreads();
+        s_sum[threadIdx.x] += v;
+        __syncthreads();
+    }
+    unsigned run = s_sum[threadIdx.x] - loc; // exclusive prefix of this thread's chunk
+    for (int b = b0; b < b1; ++b) { const unsigned c = block_valid[b]; block_valid[b] = run; run += c; }
+    if (threadIdx.x == CP_BLOCK - 1) block_valid[nblocks] = s_sum[CP_BLOCK - 1];
+}
+
+__global__ __launch_bounds__(CP_BLOCK) void order_scatter_kernel(const uint8_t* __restrict__ flags, long long n, const unsigned* __restrict__ block_off,
+                                                                 int nblocks, int32_t* __restrict__ order)
+{
+    __shared__ unsigned s_wave[CP_BLOCK / 64];
+    const long long s = (long long)blockIdx.x * CP_BLOCK + threadIdx.x;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const bool live = s < n;
+    const bool valid = live && flags[s] != 0;
+    const unsigned long long m = __ballot(valid);
+    const unsigned below = (unsigned)__builtin_popcountll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) s_wave[wv] = (unsigned)__builtin_popcountll(m);
+    __syncthreads();
+    unsigned wbase = 0;
+    for (int k = 0; k < wv; ++k) wbase += s_wave[k];
+    if (!live) return;
+    const unsigned rank_valid = wbase + below;                       // valid samples of this block before this one
+    const unsigned off_valid = block_off[blockIdx.x], total_valid = block_off[nblocks];
+    const unsigned long long before = (unsigned long long)blockIdx.x * CP_BLOCK; // samples before this block
+    const unsigned long long pos = valid ? (unsigned long long)off_valid + rank_valid
+                                         : (unsigned long long)total_valid + (before - off_valid) + (threadIdx.x - rank_valid);
+    order[pos] = (int32_t)s;
+}
+
+extern "C" int vanerf_query_order(const VanerfFrame* frame, const float* pts, int64_t n, int32_t* order, void* scratch, int64_t scratch_bytes,
+                                  void* stream)
+{
+    return guarded([&] {
+        if (n < 0) throw_error("vanerf_query_order: n = %lld < 0", (long long)n);
+        if (n == 0) return;
+        if (!frame || !pts || !order || !scratch) throw_error("vanerf_query_order: null argument");
+        if (n >= 0x7fffffffLL) throw_error("vanerf_query_order: n = %lld does not fit a 32-bit index", (long long)n);
+        const VanerfFrame& f = *frame;
+        if (!f.mask || f.hi < 1 || f.wi < 1) throw_error("vanerf_query_order: frame has no mask");
+        const int nblocks = (int)((n + CP_BLOCK - 1) / CP_BLOCK);
+        const int64_t need = n + 4 * ((int64_t)nblocks + 1) + 16;
+        if (scratch_bytes < need) throw_error("vanerf_query_order: scratch of %lld bytes, %lld needed (vanerf_query_order_scratch)", (long long)scratch_bytes, (long long)need);
+        uint8_t* flags = static_cast<uint8_t*>(scratch);
+        unsigned* block_off = reinterpret_cast<unsigned*>(flags + ((n + 15) / 16) * 16);
+        const hipStream_t st = (hipStream_t)stream;
+        hipLaunchKernelGGL(order_count_kernel, dim3(nblocks), dim3(CP_BLOCK), 0, st, f, (float)(f.wi - 1), (float)(f.hi - 1), pts, (long long)n, flags, block_off);
+        hipLaunchKernelGGL(order_scan_kernel, dim3(1), dim3(CP_BLOCK), 0, st, block_off, nblocks);
+        hipLaunchKernelGGL(order_scatter_kernel, dim3(nblocks), dim3(CP_BLOCK), 0, st, flags, (long long)n, block_off, nblocks, order);
+        HIP_CHECK(hipGetLastError());
+    });
+}
+
+extern "C" int64_t vanerf_query_order_scratch(int64_t n) { return n + 4 * ((n + CP_BLOCK - 1) / CP_BLOCK + 1) + 32; }
+
 #ifdef VANERF_STAMPS
 // Diagnostic build: same launch with a per-wave phase-cycle table [waves][12] (device pointer, zero-initialised by the caller).
 extern "C" int vanerf_debug_query_stamps(const VanerfWeights* w, const VanerfFrame* frame, const float* pts, const float* query_sdf,
@@ -880,7 +987,7 @@ extern "C" int vanerf_debug_query_stamps(const VanerfWeights* w, const VanerfFra
 {
     return guarded([&] {
         QueryParams P;
-        P.f = *frame; P.w = w->dev; P.wbytes = (unsigned)(w->n_floats * sizeof(float)); P.pts = pts; P.qsdf = query_sdf; P.qvis = query_vis; P.noise = nullptr; P.knn_in = knn_idx; P.raw = 0;
+        P.f = *frame; P.w = w->dev; P.wbytes = (unsigned)(w->n_floats * sizeof(float)); P.pts = pts; P.qsdf = query_sdf; P.qvis = query_vis; P.noise = nullptr; P.knn_in = knn_idx; P.order = nullptr; P.raw = 0;
         P.n = n; P.out = out; P.valid = nullptr; P.stamps = stamps; P.short_groups = nullptr;
         { const int ws[4] = {P.f.wi, P.f.wt, P.f.w0, P.f.w1}, hs[4] = {P.f.hi, P.f.ht, P.f.h0, P.f.h1};
           for (int i = 0; i < 4; ++i) { P.wm1[i] = (float)(ws[i] - 1); P.hm1[i] = (float)(hs[i] - 1); } }

@@ -370,14 +370,28 @@ def knn1(verts4, pts):
     return idx
 
 
-def query_samples(weights, frame, pts, query_sdf, query_vis, knn_idx, noise=None, want_valid=False, raw=False):
-    """VANeRF.query + eval_func (src/model.py:748-957, 1140-1160): (N,3),(N,),(N,)u8,(N,)i32 -> (N,5) [alpha, sdf, r, g, b]."""
+def query_order(frame, pts):
+    """vanerf_query_order: the stable partition [samples that hit the source view and its mask | the others] as an int32 permutation.
+    query_samples(order=...) then meets all-valid and all-invalid 32-sample groups only (same results, the invalid ones take its short path)."""
+    n = pts.shape[0]
+    order = torch.empty(n, dtype=torch.int32, device=pts.device)
+    nbytes = int(lib.vanerf_query_order_scratch(n))
+    scratch = torch.empty(nbytes, dtype=torch.uint8, device=pts.device)
+    check(lib.vanerf_query_order(byref(frame.c), _ptr(pts, torch.float32), n, _ptr(order, torch.int32), _ptr(scratch, torch.uint8), nbytes, _stream()))
+    return order
+
+
+def query_samples(weights, frame, pts, query_sdf, query_vis, knn_idx, noise=None, want_valid=False, raw=False, order=None):
+    """VANeRF.query + eval_func (src/model.py:748-957, 1140-1160): (N,3),(N,),(N,)u8,(N,)i32 -> (N,5) [alpha, sdf, r, g, b].
+    order: optional permutation from query_order (work order only; results are unchanged)."""
     n = pts.shape[0]
     out = torch.empty(n, 5, dtype=torch.float32, device=pts.device)
     valid = torch.empty(n, dtype=torch.uint8, device=pts.device) if want_valid else None
+    if order is not None and order.shape != (n,):
+        raise ValueError("order must hold one index per sample")
     check(lib.vanerf_query_samples(weights.handle, byref(frame.c), _ptr(pts, torch.float32), _ptr(query_sdf, torch.float32),
-                                   _ptr(query_vis, torch.uint8), _ptr(knn_idx, torch.int32), _ptr(noise, torch.float32), int(bool(raw)), n, _ptr(out),
-                                   _ptr(valid), _stream()))
+                                   _ptr(query_vis, torch.uint8), _ptr(knn_idx, torch.int32), _ptr(noise, torch.float32), _ptr(order, torch.int32),
+                                   int(bool(raw)), n, _ptr(out), _ptr(valid), _stream()))
     return (out, valid) if want_valid else out
 
 
@@ -484,6 +498,10 @@ def sample_points(rays_d, cam_pos, z):
 # ------------------------------------------------------------------------------------------------
 # one pass: rays -> coarse march -> importance -> fine march (src/model.py:1102-1360)
 # ------------------------------------------------------------------------------------------------
+# launches of at least this many samples are partitioned by validity first (query_order); below it the three small kernels cost more than they save
+PARTITION_MIN_SAMPLES = 1 << 18
+
+
 def render_pass(weights, frame, cam_tar, bounds, x0, y0, step, nx, ny, sample_per_ray_c=64, sample_per_ray_f=64, fine=True,
                 jitter=None, u=None, noise_std=0.0, generator=None, debug=False, kernel_events=None, y_step=None, reuse_coarse=True,
                 pixels=None, y_block=1):
@@ -511,7 +529,8 @@ def render_pass(weights, frame, cam_tar, bounds, x0, y0, step, nx, ny, sample_pe
         if kernel_events is not None:  # HIP events around the dominant kernel, on the stream it is launched on
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        rgba = query_samples(weights, frame, pts, q_sdf, q_vis, knn, noise)
+        order = query_order(frame, pts) if pts.shape[0] >= PARTITION_MIN_SAMPLES else None
+        rgba = query_samples(weights, frame, pts, q_sdf, q_vis, knn, noise, order=order)
         if kernel_events is not None:
             e1.record()
             kernel_events.append((e0, e1, pts.shape[0]))
