@@ -1,5 +1,6 @@
 """Builds libvanerf_hip.so (hand-written HIP for gfx950) in-tree with hipcc.  No GPU needed to build."""
 import os
+import re
 import subprocess
 import sys
 
@@ -19,6 +20,22 @@ def _stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _check_no_scratch(src, remarks):
+    """Every kernel of this library is written to live in registers: a build whose register allocation spills to scratch memory is a
+    performance cliff that still passes every test (query_kernel once went from 0 to 59 spilled VGPRs through an innocent-looking
+    change), so it fails the build.  VANERF_ALLOW_SCRATCH=1 lets experiments through."""
+    name, bad = None, []
+    for line in remarks:
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            name = m.group(1)
+        m = re.search(r"ScratchSize \[bytes/lane\]: (\d+)", line)
+        if m and int(m.group(1)) > 0:
+            bad.append((name, int(m.group(1))))
+    if bad and os.environ.get("VANERF_ALLOW_SCRATCH") != "1":
+        raise RuntimeError(f"{src}: kernels spill to scratch memory: {bad} (set VANERF_ALLOW_SCRATCH=1 to build anyway)")
+
+
 def build(force=False, verbose=False, extra=()):
     extra = tuple(extra) + tuple(os.environ.get("VANERF_HIPCC_FLAGS", "").split())
     if not force and not _stale():
@@ -29,9 +46,18 @@ def build(force=False, verbose=False, extra=()):
     for src in SOURCES:
         obj = os.path.join(HERE, "lib", src + ".o")
         cmd = [hipcc, *FLAGS, *extra, "-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
+        if src.endswith(".hip"):
+            cmd[1:1] = ["-Rpass-analysis=kernel-resource-usage", "-fno-caret-diagnostics"]  # remarks without source snippets
         if verbose:
             print(" ".join(cmd), flush=True)
-        subprocess.check_call(cmd)
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        remarks = [l for l in res.stderr.splitlines() if "kernel-resource-usage" in l]
+        other = "\n".join(l for l in res.stderr.splitlines() if "kernel-resource-usage" not in l)
+        if other.strip():
+            print(other, file=sys.stderr, flush=True)
+        if res.returncode != 0:
+            raise subprocess.CalledProcessError(res.returncode, cmd)
+        _check_no_scratch(src, remarks)
         objs.append(obj)
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
     if verbose:
