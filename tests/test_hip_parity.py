@@ -157,9 +157,10 @@ def test_composite(R, beta):
         assert (got.cpu() - want[0]).abs().max() <= 2e-5
 
 
-def test_importance_merge_bit_exact_idx(R, golden):
+@pytest.mark.parametrize("S", [64, 128, 200])  # 1, 2 and 4 samples per lane of the one-wave-per-ray kernel
+def test_importance_merge_bit_exact_idx(R, golden, S):
     g = torch.Generator().manual_seed(5)
-    Rn, S = 3000, 64
+    Rn = 3000
     contrib = torch.rand(Rn, S, generator=g) ** 6
     contrib[:10] = 0.0
     contrib[10:20, 30] = 1.0
@@ -179,9 +180,10 @@ def test_importance_merge_bit_exact_idx(R, golden):
     assert (from_coarse.sum(1) == S).all()
     assert torch.equal(zf[from_coarse].view(Rn, S), z) and torch.equal(torch.sort(zf[~from_coarse].view(Rn, S), -1)[0], torch.sort(z_new.cpu(), -1)[0])
     # random u (training): unsorted draws
-    u = torch.rand(Rn, 32, generator=g)
-    want_u = orc.importance_sample(contrib[None, :, 1:-1], z_mid[None], 32, uniform=False, u=u[None])
-    z_new_u, z_fine_u, src_u = R.importance_merge(dev(contrib), dev(z), 32, u=dev(u))
+    Sd = S // 2 + 3
+    u = torch.rand(Rn, Sd, generator=g)
+    want_u = orc.importance_sample(contrib[None, :, 1:-1], z_mid[None], Sd, uniform=False, u=u[None])
+    z_new_u, z_fine_u, src_u = R.importance_merge(dev(contrib), dev(z), Sd, u=dev(u))
     assert (z_new_u.cpu() - want_u[0]).abs().max() <= 1e-6
     assert (z_fine_u.cpu() - torch.sort(torch.cat([z, want_u[0]], -1), -1)[0]).abs().max() <= 1e-6
     # the origin map names, for every merged depth, the coarse sample (>= 0) or the draw (~index) it is -- each exactly once -- and the merge
@@ -189,7 +191,7 @@ def test_importance_merge_bit_exact_idx(R, golden):
     su, zfu = src_u.cpu().long(), z_fine_u.cpu()
     both = torch.cat([z, z_new_u.cpu()], -1)
     col = torch.where(su >= 0, su, S + (-su - 1))
-    assert torch.equal(torch.gather(both, 1, col), zfu) and torch.equal(torch.sort(col, -1)[0], torch.arange(S + 32).expand(Rn, -1))
+    assert torch.equal(torch.gather(both, 1, col), zfu) and torch.equal(torch.sort(col, -1)[0], torch.arange(S + Sd).expand(Rn, -1))
     assert (zfu[:, 1:] >= zfu[:, :-1]).all()
     tie = zfu[:, 1:] == zfu[:, :-1]
     assert (col[:, 1:][tie] > col[:, :-1][tie]).all()
@@ -201,11 +203,12 @@ def test_importance_merge_bit_exact_idx(R, golden):
     assert (zf2.cpu() - gi["merged"][0]).abs().max() <= (gi["z_mid"][0, :, -1] - gi["z_mid"][0, :, -2]).max()
 
 
-def test_importance_merge_unsorted_and_nonfinite_inputs(R):
+@pytest.mark.parametrize("S", [64, 100, 256])
+def test_importance_merge_unsorted_and_nonfinite_inputs(R, S):
     """Whatever comes in, the origin map is a permutation (the composite gathers through it) and the merge is the sort of [z | draws]:
     descending coarse depths (a camera whose far plane lies in front of the bounding box: near > far), NaN / inf contributions and depths."""
     g = torch.Generator().manual_seed(7)
-    Rn, S = 600, 64
+    Rn = 600
     contrib = torch.rand(Rn, S, generator=g) ** 4
     z = torch.sort(torch.rand(Rn, S, generator=g) * 0.3 + 0.8, -1)[0]
     z[:200] = z[:200].flip(-1)                      # descending rows (near > far)
@@ -239,7 +242,27 @@ def test_importance_merge_unsorted_and_nonfinite_inputs(R):
     assert int(k1.min()) >= 0 and int(k1.max()) < verts.shape[0] and int(f1.min()) >= 0 and int(f1.max()) < faces.shape[0]  # in range, always
 
 
-@pytest.mark.parametrize("S", [16, 72])  # 72 + 72 samples take the one-thread-per-ray importance kernel
+def test_importance_merge_more_than_256_coarse_samples(R):
+    """Beyond 256 samples a ray the one-thread-per-ray kernel runs (sorted, descending and shuffled coarse depths; fixed and random draws)."""
+    g = torch.Generator().manual_seed(11)
+    Rn, Sc, Sf = 300, 260, 24
+    contrib = torch.rand(Rn, Sc, generator=g) ** 5
+    z = torch.sort(torch.rand(Rn, Sc, generator=g) * 0.3 + 0.8, -1)[0]
+    z[100:200] = z[100:200].flip(-1)
+    z[200:210] = z[200:210][:, torch.randperm(Sc, generator=g)]
+    z_mid = 0.5 * (z[:, 1:] + z[:, :-1])
+    for u in (None, torch.rand(Rn, Sf, generator=g)):
+        kw = {} if u is None else {"u": dev(u)}
+        z_new, z_fine, src = R.importance_merge(dev(contrib), dev(z), Sf, **kw)
+        want = orc.importance_sample(contrib[None, :100, 1:-1], z_mid[None, :100], Sf, uniform=u is None, u=None if u is None else u[None, :100])
+        assert (z_new.cpu()[:100] - want[0]).abs().max() <= 1e-6
+        both = torch.cat([z, z_new.cpu()], -1)
+        col = torch.where(src.cpu().long() >= 0, src.cpu().long(), Sc + (-src.cpu().long() - 1))
+        assert torch.equal(torch.sort(col, -1)[0], torch.arange(Sc + Sf).expand(Rn, -1))
+        assert torch.equal(torch.gather(both, 1, col), z_fine.cpu()) and torch.equal(z_fine.cpu(), torch.sort(both, -1)[0])
+
+
+@pytest.mark.parametrize("S", [16, 72])  # 72 + 72 samples: two per lane in the importance and composite kernels
 def test_far_plane_in_front_of_the_bbox(R, sd_full, S):
     """near > far on the rays that hit the bounding box (zfar closer than the box): coarse depths descend, the reference sorts the merged
     depths (src/model.py:1303).  Whole pass against the oracle."""

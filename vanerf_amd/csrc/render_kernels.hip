@@ -488,117 +488,154 @@ extern "C" int vanerf_composite_merged(const float* rgba_c, const float* mesh_sd
     });
 }
 
-// importance_sample + sort-merge with one WAVE per ray (Sc, Sf <= 64: lane i holds coarse sample i and new sample i).  The rows of a ray
-// are read and written coalesced (one thread per ray touched 64 cache lines per access), the pdf total is a wave reduction and the cdf
-// a wave scan in fp64 (the sequential fp64 sums they replace differ from them by ~1e-16 relative before the rounding to fp32), each lane
-// draws one sample by binary search in the LDS copy of the cdf, and the merge is by rank: coarse sample a goes to a + #(new < z_a), new
-// sample b to b + #(coarse <= z_b) -- the stable merge of the serial kernel (coarse first on ties).  Unsorted draws (random u, or a last-bit
-// inversion) are rank-sorted first, stably, like the insertion sort they replace.
+// importance_sample + sort-merge with one WAVE per ray (Sc, Sf <= 64 * EPL: lane l holds coarse samples and new samples l, l + 64, ...).
+// The rows of a ray are read and written coalesced (one thread per ray touched 64 cache lines per access), the pdf total is a wave
+// reduction and the cdf a wave scan in fp64 (the sequential fp64 sums they replace differ from them by ~1e-16 relative before the rounding
+// to fp32), each lane draws its samples by binary search in the LDS copy of the cdf, and the merge is by rank: coarse sample a goes to
+// a + #(new < z_a), new sample b to b + #(coarse <= z_b) -- the stable merge of the serial kernel (coarse first on ties).  Unsorted draws
+// (random u, or a last-bit inversion) are rank-sorted first, stably, like the insertion sort they replace.
 constexpr int IW_RAYS = 4; // waves (rays) per block
+template <int EPL>
 __global__ __launch_bounds__(64 * IW_RAYS) void importance_merge_wave_kernel(const float* __restrict__ contrib, const float* __restrict__ z,
                                                                              const float* __restrict__ u, const float* __restrict__ t_lin, int R,
                                                                              int Sc, int Sf, float* __restrict__ z_new, float* __restrict__ z_fine,
                                                                              int32_t* __restrict__ src, int32_t* __restrict__ idx_out)
 {
-    __shared__ float s_all[IW_RAYS][6][64];
+    constexpr int N = 64 * EPL;
+    __shared__ float s_f[IW_RAYS][4][N];
+    __shared__ unsigned s_k[IW_RAYS][3][N];
+    __shared__ int s_p[IW_RAYS][N];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int r = blockIdx.x * IW_RAYS + wv;
     if (r >= R) return; // whole wave
-    float* cdf = s_all[wv][0];
-    float* zmid = s_all[wv][1];
-    float* smp = s_all[wv][2];   // new samples in draw order
-    float* srt = s_all[wv][3];   // ... sorted
-    int* perm = reinterpret_cast<int*>(s_all[wv][4]);
-    float* zc = s_all[wv][5];    // coarse depths
+    float* cdf = s_f[wv][0];
+    float* zmid = s_f[wv][1];
+    float* zc = s_f[wv][2];    // coarse depths (INFINITY beyond Sc)
+    float* smp = s_f[wv][3];   // new samples in draw order
+    unsigned* kn = s_k[wv][0];   // keys of the draws, draw order
+    unsigned* kc = s_k[wv][1];   // keys of the coarse depths
+    unsigned* ksrt = s_k[wv][2]; // keys of the draws, sorted
+    int* perm = s_p[wv];
+    // the wave's own LDS traffic only (no other wave touches this slice): wait for it, and keep the compiler from moving accesses across
+    auto lds_sync = [] { __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier(); };
     const int nb = Sc - 2;
-    const float ci = lane < Sc ? contrib[(size_t)r * Sc + lane] : 0.0f;
-    const float zi = lane < Sc ? z[(size_t)r * Sc + lane] : INFINITY;
-    const bool inner = lane >= 1 && lane <= nb;
-    double tot = inner ? (double)(ci + 1e-5f) : 0.0;
+    float ci[EPL], zi[EPL];
+    double tot = 0.0;
+#pragma unroll
+    for (int k = 0; k < EPL; ++k) {
+        const int i = k * 64 + lane;
+        ci[k] = i < Sc ? contrib[(size_t)r * Sc + i] : 0.0f;
+        zi[k] = i < Sc ? z[(size_t)r * Sc + i] : INFINITY;
+        zc[i] = zi[k];
+        if (i >= 1 && i <= nb) tot += (double)(ci[k] + 1e-5f);
+    }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) tot += __shfl_xor(tot, d);
     const float sum = (float)tot;
-    double run = inner ? (double)((ci + 1e-5f) / sum) : 0.0;
+    lds_sync();
+    double carry = 0.0;
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const double v = __shfl_up(run, d);
-        if (lane >= d) run += v;
-    }
-    const float zn = __shfl_down(zi, 1);
-    if (lane <= nb) { cdf[lane] = lane == 0 ? 0.0f : (float)run; zmid[lane] = 0.5f * (zn + zi); }
-    zc[lane] = zi; // INFINITY beyond Sc
-    __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0): the wave's own LDS writes (no other wave touches this slice)
-    __builtin_amdgcn_wave_barrier();
-    float s = INFINITY;
-    if (lane < Sf) {
-        const float uk = u ? u[(size_t)r * Sf + lane] : t_lin[lane];
-        int lo = 0, hi = nb + 1; // searchsorted(cdf, uk, right=True): first position with cdf > uk
-        while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            if (cdf[mid] <= uk) lo = mid + 1; else hi = mid;
+    for (int k = 0; k < EPL; ++k) {
+        const int i = k * 64 + lane;
+        double run = (i >= 1 && i <= nb) ? (double)((ci[k] + 1e-5f) / sum) : 0.0;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const double v = __shfl_up(run, d);
+            if (lane >= d) run += v;
         }
-        const int ip = max(lo - 1, 0), in = min(lo, nb);
-        const float cp = cdf[ip], cn = cdf[in], zp = zmid[ip], zq = zmid[in];
-        float den = cn - cp;
-        if (den < 1e-5f) den = 1.0f;
-        s = zp + ((uk - cp) / den) * (zq - zp);
-        z_new[(size_t)r * Sf + lane] = s;
-        if (idx_out) idx_out[(size_t)r * Sf + lane] = in;
+        run += carry;
+        carry = __shfl(run, 63);
+        if (i <= nb) { cdf[i] = i == 0 ? 0.0f : (float)run; zmid[i] = 0.5f * (zc[i + 1] + zi[k]); }
     }
-    smp[lane] = s;
+    lds_sync();
     // Order: a total order on the bit patterns (key), so that the positions below always form a permutation of 0 .. Sc+Sf-1 whatever the
     // values are -- a camera whose far plane lies in front of the bounding box yields DESCENDING coarse depths (near > far, the reference then
     // sorts everything: th.sort(th.cat([z, z_fine])), src/model.py:1303), and a NaN anywhere must not leave a slot of `src` unwritten (the
     // composite gathers through it).  key(a) < key(b) <=> a < b for ordinary floats; NaNs sort last.
     auto key = [](float f) { const unsigned b = __float_as_uint(f); return b ^ ((b >> 31) ? 0xffffffffu : 0x80000000u); };
-    const unsigned ks = key(s), kz = key(zi);
-    const unsigned kprev = __shfl_up(ks, 1), kzprev = __shfl_up(kz, 1);
-    const bool new_unsorted = __ballot(lane >= 1 && lane < Sf && ks < kprev) != 0ull;
-    const bool coarse_unsorted = __ballot(lane >= 1 && lane < Sc && kz < kzprev) != 0ull;
-    unsigned* kn = reinterpret_cast<unsigned*>(smp);  // keys of the draws, draw order
-    unsigned* kc = reinterpret_cast<unsigned*>(zc);   // keys of the coarse depths
-    unsigned* ksrt = reinterpret_cast<unsigned*>(srt); // keys of the draws, sorted
-    kn[lane] = ks;
-    kc[lane] = kz;
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    __builtin_amdgcn_wave_barrier();
+    float s[EPL];
+    unsigned ks[EPL], kz[EPL];
+#pragma unroll
+    for (int k = 0; k < EPL; ++k) {
+        const int j = k * 64 + lane;
+        s[k] = INFINITY;
+        if (j < Sf) {
+            const float uk = u ? u[(size_t)r * Sf + j] : t_lin[j];
+            int lo = 0, hi = nb + 1; // searchsorted(cdf, uk, right=True): first position with cdf > uk
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (cdf[mid] <= uk) lo = mid + 1; else hi = mid;
+            }
+            const int ip = max(lo - 1, 0), in = min(lo, nb);
+            const float cp = cdf[ip], cn = cdf[in], zp = zmid[ip], zq = zmid[in];
+            float den = cn - cp;
+            if (den < 1e-5f) den = 1.0f;
+            s[k] = zp + ((uk - cp) / den) * (zq - zp);
+            z_new[(size_t)r * Sf + j] = s[k];
+            if (idx_out) idx_out[(size_t)r * Sf + j] = in;
+        }
+        ks[k] = key(s[k]);
+        kz[k] = key(zi[k]);
+        smp[j] = s[k];
+        kn[j] = ks[k];
+        kc[j] = kz[k];
+    }
+    lds_sync();
+    bool new_unsorted = false, coarse_unsorted = false;
+#pragma unroll
+    for (int k = 0; k < EPL; ++k) {
+        const int j = k * 64 + lane;
+        new_unsorted = new_unsorted || __ballot(j >= 1 && j < Sf && ks[k] < kn[max(j - 1, 0)]) != 0ull;
+        coarse_unsorted = coarse_unsorted || __ballot(j >= 1 && j < Sc && kz[k] < kc[max(j - 1, 0)]) != 0ull;
+    }
     float* frow = z_fine + (size_t)r * (Sc + Sf);
     int32_t* srow = src + (size_t)r * (Sc + Sf);
     if (!coarse_unsorted) {
-        int rank = lane;
-        if (new_unsorted) { // stable rank of this draw among the draws (the insertion sort of the serial kernel)
-            rank = 0;
-            for (int jj = 0; jj < Sf; ++jj) { const unsigned o = kn[jj]; rank += (o < ks || (o == ks && jj < lane)) ? 1 : 0; }
+#pragma unroll
+        for (int k = 0; k < EPL; ++k) {
+            const int j = k * 64 + lane;
+            int rank = j;
+            if (new_unsorted) { // stable rank of this draw among the draws (the insertion sort of the serial kernel)
+                rank = 0;
+                for (int jj = 0; jj < Sf; ++jj) { const unsigned o = kn[jj]; rank += (o < ks[k] || (o == ks[k] && jj < j)) ? 1 : 0; }
+            }
+            if (j < Sf) { ksrt[rank] = ks[k]; perm[rank] = j; }
         }
-        if (lane < Sf) { ksrt[rank] = ks; perm[rank] = lane; }
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        __builtin_amdgcn_wave_barrier();
-        if (lane < Sc) { // coarse sample: position = lane + #(draws < it)
-            int lo = 0, hi = Sf;
-            while (lo < hi) { const int mid = (lo + hi) >> 1; if (ksrt[mid] < kz) lo = mid + 1; else hi = mid; }
-            frow[lane + lo] = zi; srow[lane + lo] = lane;
-        }
-        if (lane < Sf) { // draw `lane` of the sorted order: position = lane + #(coarse <= it)
-            const unsigned v = ksrt[lane];
-            const int pl = perm[lane];
-            int lo = 0, hi = Sc;
-            while (lo < hi) { const int mid = (lo + hi) >> 1; if (kc[mid] <= v) lo = mid + 1; else hi = mid; }
-            frow[lane + lo] = __shfl(s, pl); srow[lane + lo] = ~pl;
+        lds_sync();
+#pragma unroll
+        for (int k = 0; k < EPL; ++k) {
+            const int j = k * 64 + lane;
+            if (j < Sc) { // coarse sample: position = j + #(draws < it)
+                int lo = 0, hi = Sf;
+                while (lo < hi) { const int mid = (lo + hi) >> 1; if (ksrt[mid] < kz[k]) lo = mid + 1; else hi = mid; }
+                frow[j + lo] = zi[k]; srow[j + lo] = j;
+            }
+            if (j < Sf) { // draw j of the sorted order: position = j + #(coarse <= it)
+                const unsigned v = ksrt[j];
+                const int pl = perm[j];
+                int lo = 0, hi = Sc;
+                while (lo < hi) { const int mid = (lo + hi) >> 1; if (kc[mid] <= v) lo = mid + 1; else hi = mid; }
+                frow[j + lo] = smp[pl]; srow[j + lo] = ~pl;
+            }
         }
     } else { // coarse depths not ascending: full stable sort of [coarse | draws] by counting
-        int pc = 0, pn = 0;
-        for (int jj = 0; jj < Sc; ++jj) {
-            const unsigned o = kc[jj];
-            pc += (o < kz || (o == kz && jj < lane)) ? 1 : 0; // coarse before coarse
-            pn += (o <= ks) ? 1 : 0;                           // coarse before a draw (coarse first on ties)
+#pragma unroll
+        for (int k = 0; k < EPL; ++k) {
+            const int j = k * 64 + lane;
+            int pc = 0, pn = 0;
+            for (int jj = 0; jj < Sc; ++jj) {
+                const unsigned o = kc[jj];
+                pc += (o < kz[k] || (o == kz[k] && jj < j)) ? 1 : 0; // coarse before coarse
+                pn += (o <= ks[k]) ? 1 : 0;                           // coarse before a draw (coarse first on ties)
+            }
+            for (int jj = 0; jj < Sf; ++jj) {
+                const unsigned o = kn[jj];
+                pc += (o < kz[k]) ? 1 : 0;
+                pn += (o < ks[k] || (o == ks[k] && jj < j)) ? 1 : 0;
+            }
+            if (j < Sc) { frow[pc] = zi[k]; srow[pc] = j; }
+            if (j < Sf) { frow[pn] = s[k]; srow[pn] = ~j; }
         }
-        for (int jj = 0; jj < Sf; ++jj) {
-            const unsigned o = kn[jj];
-            pc += (o < kz) ? 1 : 0;
-            pn += (o < ks || (o == ks && jj < lane)) ? 1 : 0;
-        }
-        if (lane < Sc) { frow[pc] = zi; srow[pc] = lane; }
-        if (lane < Sf) { frow[pn] = s; srow[pn] = ~lane; }
     }
 }
 
@@ -610,9 +647,15 @@ extern "C" int vanerf_importance_merge(const float* contrib, const float* z, con
         if (!contrib || !z || !z_new || !z_fine || !src) throw_error("vanerf_importance_merge: null argument");
         if (!u && !t_lin) throw_error("vanerf_importance_merge: need u (random) or t_lin (uniform)");
         if (R <= 0 || Sc < 3 || Sf < 1) throw_error("vanerf_importance_merge: R=%d Sc=%d Sf=%d", R, Sc, Sf);
-        if (Sc <= 64 && Sf <= 64) { // one wave per ray
-            hipLaunchKernelGGL(importance_merge_wave_kernel, dim3((R + IW_RAYS - 1) / IW_RAYS), dim3(64 * IW_RAYS), 0, (hipStream_t)stream, contrib, z, u,
-                               t_lin, R, Sc, Sf, z_new, z_fine, src, idx);
+        const int smax = Sc > Sf ? Sc : Sf;
+        if (smax <= 256) { // one wave per ray
+            const dim3 wg((R + IW_RAYS - 1) / IW_RAYS), wb(64 * IW_RAYS);
+#define VANERF_IMPORTANCE_WAVE(EPL)                                                                                                      \
+    hipLaunchKernelGGL(importance_merge_wave_kernel<EPL>, wg, wb, 0, (hipStream_t)stream, contrib, z, u, t_lin, R, Sc, Sf, z_new, z_fine, src, idx)
+            if (smax <= 64) VANERF_IMPORTANCE_WAVE(1);
+            else if (smax <= 128) VANERF_IMPORTANCE_WAVE(2);
+            else VANERF_IMPORTANCE_WAVE(4);
+#undef VANERF_IMPORTANCE_WAVE
             HIP_CHECK(hipGetLastError());
             return;
         }
