@@ -114,3 +114,23 @@ def test_inference_is_unchanged_by_the_autograd_path():
     with torch.no_grad():
         out = _step(net, frame)
     assert not out["tex_fg_fine"].requires_grad
+
+
+def test_training_step_under_detect_anomaly():
+    """The reference trains with Trainer(detect_anomaly=True): forward + backward through both encoders, the per-frame stacks and the
+    per-sample networks must raise nothing, every parameter that receives a gradient receives a finite one, and an Adam step moves them."""
+    net = _net(0.01)
+    frame = synth.to_device(synth.make_frame(seed=5, tar_h=64, tar_w=64), "cuda")
+    opt = torch.optim.Adam([p for p in net.parameters() if p.requires_grad], lr=1e-4)
+    before = {k: v.detach().clone() for k, v in net.named_parameters()}
+    with torch.autograd.detect_anomaly():
+        out = _step(net, frame)
+        loss = sum(out[k].square().mean() for k in KEYS)
+        assert torch.isfinite(loss)
+        loss.backward()
+    with_grad = {k: p for k, p in net.named_parameters() if p.grad is not None}
+    assert all(torch.isfinite(p.grad).all() for p in with_grad.values())
+    for prefix in ("geo_encoder.", "tex_encoder.", "geo_vis_fusion.", "mlp_geo.", "tex_vis_fusion.", "ibr_compress_gfeat.", "sigmoid_beta"):
+        assert any(k.startswith(prefix) and p.grad.abs().sum() > 0 for k, p in with_grad.items()), prefix
+    opt.step()
+    assert sum(int(not torch.equal(before[k], p.detach())) for k, p in with_grad.items()) >= 0.9 * len(with_grad)
