@@ -422,12 +422,24 @@ def composite_merged(rgba_c, sdf_c, rgba_n, sdf_n, src, z_fine, beta, want_contr
     return color, depth, alpha, contrib, sdf
 
 
+_T_LIN = {}
+
+
+def _t_lin(S, dev):
+    """th.linspace(0, 1, S) on the device, built once per (S, device): a host -> device copy from pageable memory waits for everything
+    queued on the stream, which stalled the host twice per pass (tools/perf_host_enqueue.py)."""
+    key = (int(S), torch.device(dev))
+    if key not in _T_LIN:
+        _T_LIN[key] = torch.linspace(0.0, 1.0, steps=int(S)).to(dev)
+    return _T_LIN[key]
+
+
 def importance_merge(contrib, z, sample_per_ray, u=None, want_idx=False):
     """importance_sample + sort-merge (src/model.py:1424-1462, 1301-1307).  contrib, z: (R,Sc) -> z_new (R,Sf), z_fine (R,Sc+Sf), src."""
     R, Sc = z.shape
     Sf = int(sample_per_ray)
     dev = z.device
-    t_lin = torch.linspace(0.0, 1.0, steps=Sf).to(dev) if u is None else None
+    t_lin = _t_lin(Sf, dev) if u is None else None
     z_new = torch.empty(R, Sf, dtype=torch.float32, device=dev)
     z_fine = torch.empty(R, Sc + Sf, dtype=torch.float32, device=dev)
     src = torch.empty(R, Sc + Sf, dtype=torch.int32, device=dev)
@@ -443,7 +455,7 @@ def importance_from_midpoints(contrib_inner, z_mid, sample_per_ray, u=None, want
     assert z_mid.shape == (Rn, nb + 1)
     dev = z_mid.device
     Sf = int(sample_per_ray)
-    t_lin = torch.linspace(0.0, 1.0, steps=Sf).to(dev) if u is None else None
+    t_lin = _t_lin(Sf, dev) if u is None else None
     z_new = torch.empty(Rn, Sf, dtype=torch.float32, device=dev)
     idx = torch.empty(Rn, Sf, dtype=torch.int32, device=dev) if want_idx else None
     check(lib.vanerf_importance_sample(_ptr(contrib_inner, torch.float32), _ptr(z_mid, torch.float32), _ptr(u, torch.float32), _ptr(t_lin), Rn, nb, Sf,
@@ -476,7 +488,7 @@ def ray_setup(cam_tar, bounds, x0, y0, step, nx, ny, S, jitter=None, device=None
     near, far = torch.empty(R, dtype=torch.float32, device=dev), torch.empty(R, dtype=torch.float32, device=dev)
     hit = torch.empty(R, dtype=torch.uint8, device=dev)
     z = torch.empty(R, S, dtype=torch.float32, device=dev)
-    t_lin = torch.linspace(0.0, 1.0, steps=S).to(dev)
+    t_lin = _t_lin(S, dev)
     cam_args = (_farr(inv_K_T.reshape(-1).tolist(), 9), _farr(RT[0, :3, :4].reshape(-1).tolist(), 12), float(cam_tar["znear"]),
                 float(cam_tar["zfar"]), _farr(bounds.detach().reshape(-1).tolist(), 6), int(S), _ptr(t_lin), _ptr(jitter, torch.float32),
                 _ptr(index), _ptr(rays_d), _ptr(cam_pos), _ptr(near), _ptr(far), _ptr(hit), _ptr(z), _stream())
