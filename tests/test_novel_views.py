@@ -179,3 +179,72 @@ def test_render_video_on_hip_path(tmp_path):
         diff = np.abs(img[:, 256:].astype(np.int16) - rgb[fi].astype(np.int16))
         assert diff.max() <= 1 and (diff > 0).mean() < 1e-2
     assert (tmp_path / "video" / "seq" / "3_nvs.gif").exists()
+
+
+@pytest.mark.gpu
+def test_per_frame_caches_follow_their_inputs():
+    """render_pifu_nerf keeps the encoders' feature maps and the per-frame tables between calls (one call per target view of an orbit).  The
+    caches must notice: another image, the same image tensor modified in place, a new image that the allocator puts where the old one was,
+    and changed encoder weights -- each compared with a fresh network that has no history."""
+    from vanerf_amd.config import default_config
+    from vanerf_amd.model import VANeRF
+    torch.manual_seed(0)
+    cfg = default_config()
+    cfg["models"]["VANeRF"]["dr_kwargs"].update(sample_per_ray_c=8, sample_per_ray_f=8)
+    sd = synth.make_full_weights(0)
+
+    def fresh():
+        n = VANeRF(cfg).cuda().eval()
+        n.load_state_dict(sd, strict=False)
+        return n
+
+    def render(n, trb, frame):
+        with torch.no_grad():
+            return n.render_pifu_nerf(None, n, trb["im"], trb["cam"], trb["hand_type"], trb["targets"], frame["cam_tar"], level=1,
+                                      sp_data=dict(trb["sp_data"]), fine=True, uniform=True, sample_per_ray_c=8, sample_per_ray_f=8,
+                                      src_foreground_mask=trb["src_foreground_mask"], bounds=trb["dr_data"]["bounds"], mask_at_box=None)["tex_fg_fine"]
+
+    same = lambda x, y: (x - y).abs().max().item() <= 2e-4   # two networks: MIOpen may pick different convolution solvers
+    differs = lambda x, y: (x - y).abs().max().item() > 1e-3
+    net = fresh()
+    enc_state = {k: v.clone() for k, v in net.state_dict().items() if k.startswith(("geo_encoder.", "tex_encoder."))}
+    frame = synth.to_device(synth.make_frame(seed=3, tar_h=32, tar_w=32), "cuda")
+    trb = synth.to_tr_batch(frame)
+    a0 = render(net, trb, frame)
+    calls = []
+    orig = net.geo_encoder.forward
+    net.geo_encoder.forward = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    assert torch.equal(render(net, trb, frame), a0) and not calls                       # same inputs: no encoder run, same image
+    # (1) the image tensor modified in place
+    trb["im"].mul_(0.5)
+    b = render(net, trb, frame)
+    assert calls and differs(b, a0)
+    ref = fresh()
+    ref.load_state_dict(enc_state, strict=False)
+    assert same(b, render(ref, trb, frame))
+    # (2) a new image tensor, allocated where the old one was
+    shape, ptr = trb["im"].shape, trb["im"].data_ptr()
+    new_im = None
+    trb["im"] = None
+    torch.cuda.synchronize()
+    for _ in range(4):
+        cand = torch.rand(shape, device="cuda")
+        if cand.data_ptr() == ptr:
+            new_im = cand
+            break
+    if new_im is None:  # the allocator did not cooperate: any new tensor still has to be noticed
+        new_im = torch.rand(shape, device="cuda")
+    trb["im"] = new_im
+    c = render(net, trb, frame)
+    ref = fresh()
+    ref.load_state_dict(enc_state, strict=False)
+    assert same(c, render(ref, trb, frame)) and differs(c, b)
+    # (3) encoder weights changed in place (a training step, load_state_dict)
+    with torch.no_grad():
+        g = torch.Generator(device="cuda").manual_seed(1)
+        for prm in net.geo_encoder.parameters():  # (scaling one convolution would be undone by the normalisation behind it)
+            prm.add_(0.05 * torch.randn(prm.shape, device="cuda", generator=g))
+    d = render(net, trb, frame)
+    ref = fresh()
+    ref.load_state_dict({k: v for k, v in net.state_dict().items() if k.startswith(("geo_encoder.", "tex_encoder."))}, strict=False)
+    assert same(d, render(ref, trb, frame)) and differs(d, c)

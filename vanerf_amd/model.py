@@ -161,6 +161,7 @@ class VANeRF(nn.Module):
         self.precision = model_cfg.get("mfma_precision", "fp32")  # "fp32" | "bf16x3" (renderer.PRECISIONS); not a reference key
         self._packed = None  # (version key, PackedWeights)
         self._frame_cache = None
+        self._enc_cache = None  # (key, feat_geo, feat_tex, image)
 
     # ---- image features (src/model.py:700-746) ---------------------------------------------------------------------
     def attach_im_feat(self, im, return_val=False):
@@ -195,6 +196,18 @@ class VANeRF(nn.Module):
         if return_val:
             return self.feat_tex
 
+    def encoded(self, im):
+        """Both encoders' feature maps of a source image.  Outside autograd they are kept for as long as the caller passes the same (unmodified)
+        image tensor and the encoders' parameters and buffers do not change (eval mode only): render_pifu_nerf is called once per target view (120 times per orbit) and the
+        reference runs both encoders in every call (src/model.py:1049-1050)."""
+        if torch.is_grad_enabled() or self.training:  # (in train mode a forward also updates the BatchNorm statistics)
+            return self.attach_geo_feat(im, return_val=True), self.attach_tex_feat(im, return_val=True)
+        state = [t for enc in (self.geo_encoder, self.tex_encoder) if enc is not None for t in (*enc.parameters(), *enc.buffers())]
+        key = (im.data_ptr(), im._version, tuple(im.shape), self.ds_geo, self.ds_tex, tuple((t.data_ptr(), t._version) for t in state))
+        if self._enc_cache is None or self._enc_cache[0] != key:
+            self._enc_cache = (key, self.attach_geo_feat(im, return_val=True), self.attach_tex_feat(im, return_val=True), im)
+        return self._enc_cache[1], self._enc_cache[2]
+
     def detach_im_feat(self):
         self.feat_geo = None
         self.feat_tex = None
@@ -216,12 +229,14 @@ class VANeRF(nn.Module):
     def frame_data(self, img_in, cam_in, targets, feat_geo, feat_tex, sp_data, fg_mask):
         """Per-source-frame device data (vertex features, visibility, acceleration structure); cached on the identity of its inputs
         because render_pifu_nerf / render_novel_views call batch_render_pifu_nerf many times per source frame."""
-        key = (img_in.data_ptr(), feat_geo[0].data_ptr(), feat_tex.data_ptr(), targets["vert_world"].data_ptr(), cam_in["KRT"].data_ptr(),
-               sp_data["kpt3d"].data_ptr(), fg_mask.data_ptr(), tuple(p._version for p in self.tex_vis_fusion.parameters()))
+        # identity AND version of every input; the tensors themselves are kept with the entry, so none of their addresses can be handed to a
+        # different tensor while the entry is alive (an address alone would match a new batch that the allocator placed where the old one was)
+        deps = (img_in, feat_geo[0], feat_geo[1], feat_tex, targets["vert_world"], targets["face_world"], cam_in["KRT"], sp_data["kpt3d"], fg_mask)
+        key = tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in deps) + (tuple(p._version for p in self.tex_vis_fusion.parameters()),)
         if self._frame_cache is None or self._frame_cache[0] != key:
             sd = {"tex_vis_fusion." + k: v for k, v in self.tex_vis_fusion.state_dict().items()}
             fd = R.FrameData(sd, img_in, feat_geo, feat_tex, fg_mask, cam_in, targets, sp_data, self.kwargs["sp_args"])
-            self._frame_cache = (key, fd)
+            self._frame_cache = (key, fd, deps)
         return self._frame_cache[1]
 
     # ---- per-sample query (src/model.py:748-877) ---------------------------------------------------------------------
@@ -335,10 +350,12 @@ class VANeRF(nn.Module):
             out.update({"tex_fg_fine": o["color_fine"].view(1, out_h, out_w, 3).permute(0, 3, 1, 2), "depth_fine": o["depth_fine"].view(1, out_h, out_w),
                         "alpha_fine": o["alpha_fine"].view(1, out_h, out_w), "sdf": o["sdf"].view(1, out_h, out_w)})
         index = o["index"][None]
+        # largest pixel index of the pass, on the host when the rays are a grid (reading it back would stall the host behind the whole pass)
+        index_max = int(index.max()) if pixels is not None else (y0 + (ny - 1) * step) * int(width) + x0 + (nx - 1) * step
 
         def gather(t, ch):  # GT gathers at `index` (src/model.py:1361-1418); the reference indexes source-sized tensors with target
             flat = t.reshape(t.shape[0], ch, -1)  # pixel indices and fails for targets larger than the source -- guarded here
-            if int(index.max()) >= flat.shape[-1]:
+            if index_max >= flat.shape[-1]:
                 return None
             return torch.gather(flat, 2, index[:, None].expand(-1, ch, -1)).view(t.shape[0], ch, out_h, out_w)
 
@@ -370,8 +387,7 @@ class VANeRF(nn.Module):
                          tar_img=None, **config):
         """src/model.py:1026-1100.  The reference renders stride^2 pixel-interleaved passes and pixel_shuffles them because its unfused
         intermediates do not fit; rays are independent, so ONE full-resolution launch (level 1) yields the same image."""
-        feat_geo = net.attach_geo_feat(img_in, return_val=True)
-        feat_tex = net.attach_tex_feat(img_in, return_val=True)
+        feat_geo, feat_tex = net.encoded(img_in)
         out = net.batch_render_pifu_nerf(net, img_in, cam_in, hand_type, targets, 1, cam_tar, 1, 0, tar_img, feat_geo, feat_tex, None, sp_data,
                                          objcenter, **config)
         if "input_densepose" in out and self is not None and hasattr(self, "discriminator"):
