@@ -76,3 +76,20 @@ def test_orbit_cameras():
     assert len(cams) == 20 and cams[0]["w2cs"].shape == (4, 4) and cams[0]["intrinsics"].shape == (1, 4, 4)
     assert torch.allclose(cams[0]["w2cs"] @ cams[0]["c2ws"], torch.eye(4), atol=1e-5)
     assert not torch.allclose(cams[0]["w2cs"], cams[7]["w2cs"])
+
+
+def test_bicubic_upsampling_as_matrix_products_matches_the_library_call():
+    """HourGlass up-sampling under autograd (vanerf_amd/encoders.py:_bicubic_up2) == F.interpolate(bicubic, align_corners=True), values and gradients."""
+    import torch.nn.functional as F
+    from vanerf_amd.encoders import _bicubic_up2
+    g = torch.Generator().manual_seed(0)
+    for shape in ((1, 5, 16, 12), (2, 3, 7, 9), (1, 4, 2, 2)):
+        x = torch.randn(shape, generator=g, requires_grad=True)
+        a, b = _bicubic_up2(x), F.interpolate(x, scale_factor=2, mode="bicubic", align_corners=True)
+        assert a.shape == b.shape and (a - b).abs().max() <= 2e-6
+        go = torch.randn(a.shape, generator=g)
+        ga, = torch.autograd.grad(a, x, go)
+        gb, = torch.autograd.grad(b, x, go)
+        assert (ga - gb).abs().max() <= 2e-5
+        with torch.no_grad():
+            assert torch.equal(_bicubic_up2(x.detach()), b.detach())  # inference: the library call itself

@@ -20,9 +20,21 @@ NUM_V = 779  # vertices per hand: the "other hand" twin of vertex i is (i + 779)
 
 
 def sample_map(feat, xy):
-    """feat_sample (src/utils.py:136-151): (1,C,H,W) map at (N,2) coordinates in [-1,1] -> (N,C); bilinear, border, align_corners."""
-    out = F.grid_sample(feat, xy.view(1, -1, 1, 2), mode="bilinear", padding_mode="border", align_corners=True)
-    return out.view(feat.shape[1], -1).t()
+    """feat_sample (src/utils.py:136-151): (1,C,H,W) map at (N,2) coordinates in [-1,1] -> (N,C); bilinear, border, align_corners.
+    Written as four row gathers from the channel-last map: the coordinates carry no gradient here, and the backward of a row gather is
+    an index_add of contiguous C-float rows, where grid_sampler_2d_backward issues one strided atomic per channel and tap (4.2 ms per
+    call on the 64-channel map, a quarter of the training step)."""
+    _, C, H, W = feat.shape
+    with torch.no_grad():
+        x = ((xy[:, 0] + 1.0) * (0.5 * (W - 1))).clamp(0.0, W - 1.0)
+        y = ((xy[:, 1] + 1.0) * (0.5 * (H - 1))).clamp(0.0, H - 1.0)
+        x0, y0 = x.floor(), y.floor()
+        wx, wy = (x - x0)[:, None], (y - y0)[:, None]
+        x0, y0 = x0.long(), y0.long()
+        x1, y1 = (x0 + 1).clamp(max=W - 1), (y0 + 1).clamp(max=H - 1)
+    rows = feat[0].permute(1, 2, 0).reshape(H * W, C)
+    tap = lambda yy, xx: rows.index_select(0, yy * W + xx)
+    return (tap(y0, x0) * (1.0 - wx) + tap(y0, x1) * wx) * (1.0 - wy) + (tap(y1, x0) * (1.0 - wx) + tap(y1, x1) * wx) * wy
 
 
 def _linear_wn(P, prefix, x):
@@ -74,7 +86,9 @@ def positional_encoding(pts, kpt3d, extrin, levels=3, scale=1.0, sigma=0.1):
 def _nearest_rows(table, vis, idx):
     """KNN_vis (src/networks.py:27-33) with the nearest-vertex index given: rows of the nearest vertex and of its twin, x visibility."""
     twin = (idx + NUM_V) % (2 * NUM_V)
-    return table[idx] * vis[idx, None], table[twin] * vis[twin, None], vis[idx, None], vis[twin, None]
+    vi, vt = vis[idx, None], vis[twin, None]
+    # index_select: its backward is an index_add (atomics); table[idx] goes through a sort-based index_put (3.4 ms per call, 12 calls a step)
+    return table.index_select(0, idx) * vi, table.index_select(0, twin) * vt, vi, vt
 
 
 def geo_fusion(P, geo_maps, pix, vert_xy, idx, vert_vis, q_vis, q_sdf, pre="geo_vis_fusion."):
