@@ -349,6 +349,20 @@ def test_query_samples_vs_oracle(R, sd_full, seed, half):
     assert (sig_ref - sig_got).abs().max() * beta <= TOL
 
 
+@pytest.mark.parametrize("wseed,fseed,orbit,half", [(1, 7, 25.0, False), (2, 8, 140.0, True), (3, 9, 60.0, False)])
+def test_query_samples_other_weights_and_poses(R, wseed, fseed, orbit, half):
+    """Other random weights, hand poses and target orbits than the fixtures the kernels were developed on: both precisions against the oracle."""
+    sd = synth.make_full_weights(wseed)
+    frame = _frame(fseed, 64, orbit, half)
+    pts = _points_near_mesh(frame, 2048 + 5, seed=wseed)
+    ref, valid, got, gvalid, gknn, fdat, _ = _query_both(R, sd, frame, pts)
+    assert torch.equal(gknn, orc.knn1(pts, frame["targets"]["vert_world"][0])) and torch.equal(gvalid, valid)
+    assert (got - ref).abs().max() <= TOL
+    q_sdf, q_vis, knn = R.mesh_query_accel(fdat.accel, fdat.verts3, fdat.faces, fdat.vert_vis, dev(pts))  # (bit-exact with the oracle's, tested above)
+    got1 = R.query_samples(R.PackedWeights(sd, mode=1), fdat, dev(pts), q_sdf, q_vis, knn).cpu()
+    assert (got1 - ref).abs().max() <= TOL
+
+
 def test_query_samples_split_bf16_vs_oracle(R, sd_full):
     """mode 1 (W_hi X_hi + W_hi X_lo + W_lo X_hi on bf16 MFMA, fp32 accumulate) holds the same 1e-4 bar; plain bf16 would not (4e-3)."""
     frame = _frame(3, 64, 8.0, True)
