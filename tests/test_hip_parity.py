@@ -675,3 +675,17 @@ def test_edge_cases_and_config3(R, sd_full, precision):
         R.query_samples(w, fdat, p.double(), s, v, k)
     with pytest.raises(ValueError):
         R.query_samples(w, fdat, p.cpu(), s, v, k)
+
+
+def test_host_copies_follow_the_device_tensor(R):
+    """Camera matrices and bounds reach the kernels by value; their host copies are remembered per (address, version) of the device tensor."""
+    t = dev(torch.arange(12.0).view(3, 4))
+    a = R.host_copy(t)
+    assert torch.equal(a, t.cpu()) and R.host_copy(t.view(1, 3, 4)).shape == (1, 3, 4)
+    t.mul_(2.0)                                     # modified in place: a new copy
+    assert torch.equal(R.host_copy(t), t.cpu()) and torch.equal(R.host_copy(t.view(2, 6)), t.cpu().view(2, 6))
+    assert torch.equal(R.host_copy(t.t()), t.cpu().t())           # not contiguous: never taken from the table
+    many = [dev(torch.rand(3, 3)) for _ in range(5)]
+    R.prefetch_host_copies(many + [t])
+    for m in many:
+        assert torch.equal(R.host_copy(m), m.cpu())

@@ -82,6 +82,9 @@ def render_novel_views(net, cameras, tr_batch, only_renderings=False, rank=0, wo
         net.attach_im_feat(tr_batch["im"])  # once per source frame (src/model.py:517)
     tr_batch["dr_data"]["tar"] = None
     mine = frames_of_rank(len(cameras), rank, world)
+    if render_fn is _default_render and mine:  # the camera matrices go to the kernels by value: one read-back for the whole orbit, not one per frame
+        from . import renderer as R
+        R.prefetch_host_copies([cameras[fi][k] for fi in mine for k in ("intrinsics", "w2cs")] + [tr_batch["dr_data"]["bounds"]])
     frames = []
     for fi in mine:
         camera = cameras[fi]

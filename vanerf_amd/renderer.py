@@ -422,6 +422,43 @@ def composite_merged(rgba_c, sdf_c, rgba_n, sdf_n, src, z_fine, beta, want_contr
     return color, depth, alpha, contrib, sdf
 
 
+_HOST = {}
+
+
+def _host_key(t):
+    return (t.data_ptr(), t._version, t.numel(), t.dtype)  # contiguous tensors only: a reshaped view of the same memory is the same numbers
+
+
+def host_copy(t):
+    """fp32 CPU copy of a small tensor (camera matrices, bounds: they are passed to the kernels by value).  Reading a device tensor back
+    waits for everything queued before it, so copies of device tensors are remembered while the tensor is alive and unmodified; a caller
+    that knows its next cameras hands them to prefetch_host_copies first (one read-back for all of them)."""
+    if not t.is_cuda or not t.is_contiguous():
+        return t.detach().to("cpu", torch.float32)
+    key = _host_key(t)
+    hit = _HOST.get(key)
+    if hit is None:
+        if len(_HOST) >= 1024:
+            _HOST.clear()
+        hit = _HOST[key] = (t.detach().reshape(-1).to("cpu", torch.float32), t)  # (the tensor itself is kept: its address stays its own)
+    return hit[0].view(t.shape)
+
+
+def prefetch_host_copies(tensors):
+    """One device -> host transfer for many small tensors; host_copy() then finds them without touching the device."""
+    todo = [t for t in tensors if t.is_cuda and t.is_contiguous() and _host_key(t) not in _HOST]
+    if not todo:
+        return
+    if len(_HOST) + len(todo) >= 1024:
+        _HOST.clear()
+    flat = torch.cat([t.detach().reshape(-1).to(torch.float32) for t in todo]).cpu()
+    off = 0
+    for t in todo:
+        n = t.numel()
+        _HOST[_host_key(t)] = (flat[off:off + n].clone(), t)
+        off += n
+
+
 _T_LIN = {}
 
 
@@ -478,8 +515,7 @@ def ray_setup(cam_tar, bounds, x0, y0, step, nx, ny, S, jitter=None, device=None
     pixels: optional explicit (R,2) int32 device tensor of (x, y) (training patches); then nx*ny must equal R.
     y_step, y_block: rows are y0 + (iy // y_block) * y_step + (iy % y_block) * step (multi-GPU shards: blocks of y_block rows)."""
     dev = device or bounds.device
-    K = cam_tar["K"].detach().to("cpu", torch.float32)
-    RT = cam_tar["RT"].detach().to("cpu", torch.float32)
+    K, RT = host_copy(cam_tar["K"]), host_copy(cam_tar["RT"])
     inv_K_T = torch.inverse(K[:, :3, :3]).transpose(1, 2)[0].contiguous()  # th.inverse(...).transpose(1, 2), model.py:1208
     R = nx * ny
     index = torch.empty(R, dtype=torch.int64, device=dev)
@@ -490,7 +526,7 @@ def ray_setup(cam_tar, bounds, x0, y0, step, nx, ny, S, jitter=None, device=None
     z = torch.empty(R, S, dtype=torch.float32, device=dev)
     t_lin = _t_lin(S, dev)
     cam_args = (_farr(inv_K_T.reshape(-1).tolist(), 9), _farr(RT[0, :3, :4].reshape(-1).tolist(), 12), float(cam_tar["znear"]),
-                float(cam_tar["zfar"]), _farr(bounds.detach().reshape(-1).tolist(), 6), int(S), _ptr(t_lin), _ptr(jitter, torch.float32),
+                float(cam_tar["zfar"]), _farr(host_copy(bounds).reshape(-1).tolist(), 6), int(S), _ptr(t_lin), _ptr(jitter, torch.float32),
                 _ptr(index), _ptr(rays_d), _ptr(cam_pos), _ptr(near), _ptr(far), _ptr(hit), _ptr(z), _stream())
     if pixels is not None:
         assert pixels.shape == (R, 2)
