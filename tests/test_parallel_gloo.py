@@ -107,3 +107,24 @@ def test_two_rank_gradient_average():
     for rank_res in res:
         for got, w in zip(rank_res[2], want):
             assert torch.allclose(got, w, atol=1e-6)
+
+
+H4 = 64
+
+
+def _worker4(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    img = torch.arange(H4 * W * 3, dtype=torch.float32).view(H4, W, 3)
+    y0, step, ny, yb = shard_rows(H4, world, rank)
+    tile = img[rank_rows(H4, world, rank)].reshape(-1, 3)
+    full = gather_image(tile, H4, W, world)
+    q.put((rank, torch.equal(full, img), (y0, step, ny, yb)))
+    dist.destroy_process_group()
+
+
+def test_four_rank_gather_of_row_blocks():
+    """The layout bench.py --gpus 4 uses: 8-row blocks dealt round robin (block b -> rank b mod 4), one all_gather, de-interleaved by blocks."""
+    res = _run_ranks(_worker4, world=4)
+    assert [r[1] for r in res] == [True] * 4
+    assert [r[2] for r in res] == [(8 * r, 32, 16, 8) for r in range(4)]
