@@ -41,6 +41,32 @@ def save(name, **arrs):
     print(f"{name}.npz  {os.path.getsize(path) / 1024:.1f} KiB")
 
 
+class _Recording:
+    """Stands in for a module (`th`, `np`, `np.random`) in the reference's namespace: every attribute is the real one, except that calls
+    of the names in `record` append their result to `log` -- the random numbers of a training pass (src/model.py:1182, 1229, 1443, 1156)."""
+
+    def __init__(self, mod, record, log, children=None):
+        self._mod, self._record, self._log, self._children = mod, record, log, children or {}
+
+    def __getattr__(self, k):
+        if k in self._children:
+            return self._children[k]
+        v = getattr(self._mod, k)
+        if k not in self._record:
+            return v
+
+        def call(*a, **kw):
+            r = v(*a, **kw)
+            self._log.append((k, r.clone() if isinstance(r, torch.Tensor) else np.array(r)))
+            return r
+        return call
+
+
+def checksum(v):
+    v = v.detach().double().flatten()
+    return torch.stack([v.sum(), v.abs().sum(), v[0], v[-1]])
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -70,6 +96,15 @@ def main():
     cfg = json.load(open(os.path.join("/root/reference", "configs", "vanerf.json")))
     torch.manual_seed(0)
     net = M.VANeRF(cfg).eval()
+    # init_weights (src/model.py:660-698) as the reference leaves a fresh module after torch.manual_seed(0): a checksum of every entry
+    # of the state_dict, and the encoders' feature maps of a seeded image with exactly these weights (sub-sampled values + checksums)
+    save("init_checksums", **{k: checksum(v) for k, v in net.state_dict().items()})
+    img_e = torch.rand(1, 3, 256, 256, generator=torch.Generator().manual_seed(21))
+    with torch.no_grad():
+        eg = net.attach_geo_feat(img_e, return_val=True)
+        et = net.attach_tex_feat(img_e, return_val=True)
+    save("encoder_values", geo0_sub=eg[0][0, ::8, ::4, ::4], geo1_sub=eg[1][0, :, ::16, ::16], tex_sub=et[0, :, ::8, ::8],
+         geo0_sum=checksum(eg[0]), geo1_sum=checksum(eg[1]), tex_sum=checksum(et))
     # The reference's own init leaves alpha == 0 and colours ~1e-2 (see synth.make_hot_weights): load well-scaled
     # weights for the per-sample networks into the reference module; the per-frame TexVisFusion convs keep the
     # reference init (rebuilt by recipe + checksum in the tests).
@@ -201,27 +236,73 @@ def main():
         save("ibr_head_v2", rgb_feats=rf, ray_diffs=rd, proj_mask=pm, out=net.mlp_tex(rf.clone(), rd, pm))
 
     # ---- (viii) whole pass ------------------------------------------------------------------------
-    def run_pass(frame, level, stride_xy, S, tag, keep_inter):
+    def run_pass(frame, level, stride_xy, S, tag, keep_inter, gt=False):
         calls.clear()
         strd = torch.tensor([stride_xy], dtype=torch.float32)
+        extra = {}
+        if gt:  # GT gathers of src/model.py:1361-1418: a seeded target image and target mask
+            gg = torch.Generator().manual_seed(31)
+            hw = (int(frame["cam_tar"]["height"]), int(frame["cam_tar"]["width"]))
+            extra = dict(tar_img=torch.rand(1, 3, *hw, generator=gg), msk=torch.rand(1, *hw, generator=gg) > 0.5)
         with torch.no_grad():
             o = M.VANeRF.batch_render_pifu_nerf(net, frame["img_in"], frame["cam_in"], frame["hand_type"], frame["targets"], 1,
-                                                frame["cam_tar"], level, strd, None, frame["feat_geo"], frame["feat_tex"], None,
+                                                frame["cam_tar"], level, strd, extra.get("tar_img"), frame["feat_geo"], frame["feat_tex"], None,
                                                 copy.copy(frame["sp_data"]), None, fine=True, uniform=True, sample_per_ray_c=S,
                                                 sample_per_ray_f=S, src_foreground_mask=frame["src_foreground_mask"],
-                                                bounds=frame["bounds"], mask_at_box=None)
+                                                bounds=frame["bounds"], mask_at_box=None, **({"msk": extra["msk"]} if gt else {}))
         keep = {k: o[k] for k in ("tex_fg", "depth", "alpha", "tex_fg_fine", "depth_fine", "alpha_fine", "sdf", "vert_vis")}
+        if gt:
+            keep.update(gt_tar_img_in=extra["tar_img"], gt_msk_in=extra["msk"], **{"gt_" + k: o[k] for k in ("tar_img", "tar_alpha", "input_mask", "img_in", "vis_img")})
         if keep_inter:
             keep.update(pts_coarse=calls[0]["points"], sdf_coarse=calls[0]["sdf"], vis_coarse=calls[0]["vis"],
                         pts_fine=calls[1]["points"], sdf_fine=calls[1]["sdf"], vis_fine=calls[1]["vis"])
         save(tag, level=level, stride_xy=np.asarray(stride_xy), S=S, **keep)
         return o
 
-    run_pass(frame, 4, [3, 5], 16, "pass_8x8_s16", True)
+    run_pass(frame, 4, [3, 5], 16, "pass_8x8_s16", True, gt=True)
     frame_b = synth.make_frame(seed=5, tar_h=64, tar_w=64, orbit_deg=70.0, half_mask=True)
     run_pass(frame_b, 3, [1, 2], 24, "pass_16x16_s24_bvv", False)
     frame_c = synth.make_frame(seed=11, tar_h=256, tar_w=256, orbit_deg=15.0)
     run_pass(frame_c, 3, [0, 0], 64, "pass_64x64_s64", False)
+
+    # ---- (viii, training) one training-mode pass with the RNG draws recorded: 16x16 window (train_out_h/w), stratified depths,
+    # random importance samples, rand_noise_std on both marches, GT gathers, and the loss of compute_error (vggloss=None) -----------
+    log = []
+    np_rec = _Recording(np, (), log, children={"random": _Recording(np.random, ("randint",), log)})
+    th_rec = _Recording(torch, ("rand_like", "rand", "randn_like"), log)
+    M.th, M.np, real_th, real_np = th_rec, np_rec, M.th, M.np
+    net.train()
+    net.train_out_h = net.train_out_w = 16
+    gg = torch.Generator().manual_seed(41)
+    tar_img = torch.rand(1, 3, 64, 64, generator=gg)
+    yy, xx = torch.meshgrid(torch.arange(64), torch.arange(64), indexing="ij")
+    msk = (((xx - 30) ** 2 + (yy - 34) ** 2) < 14 ** 2)[None]
+    St = 16
+    torch.manual_seed(7)
+    np.random.seed(7)
+    try:
+        with torch.no_grad():
+            o = M.VANeRF.batch_render_pifu_nerf(net, frame["img_in"], frame["cam_in"], frame["hand_type"], frame["targets"], 1,
+                                                frame["cam_tar"], 5, torch.tensor([[3, 1]]), tar_img, frame["feat_geo"], frame["feat_tex"], None,
+                                                copy.copy(frame["sp_data"]), None, fine=True, uniform=False, rand_noise_std=0.01,
+                                                sample_per_ray_c=St, sample_per_ray_f=St, msk=msk,
+                                                src_foreground_mask=frame["src_foreground_mask"], bounds=frame["bounds"], mask_at_box=None)
+    finally:
+        M.th, M.np = real_th, real_np
+        net.eval()
+        net.train_out_h = net.train_out_w = 64
+    names = [k for k, _ in log]
+    assert names == ["randint", "rand_like", "randn_like", "rand", "randn_like"], names  # model.py:1182, 1229, 1156, 1443, 1156
+    draws = dict(pick=log[0][1], jitter=log[1][1], noise_c=log[2][1], u=log[3][1], noise_f=log[4][1])
+    o["tex"] = o["tex_cal"] = o["tex_fg"]
+    o["tex_fine"] = o["tex_cal_fine"] = o["tex_fg_fine"]
+    lambdas = cfg["models"]["VANeRF"]["lambdas"]
+    loss, err = U.compute_error(inter_loss=None, out_nerf=o, vggloss=None, lambdas=lambdas)
+    lam2 = dict(lambdas, lambda_mloss=0.5, lambda_l2=2.0, lambda_lp=0.3)  # the terms the shipped config switches off
+    loss2, err2 = U.compute_error(inter_loss=None, out_nerf=o, vggloss=None, lambdas=lam2)
+    save("pass_train_16x16_s16", S=St, tar_img_in=tar_img, msk_in=msk, **draws,
+         **{k: o[k] for k in ("tex_fg", "depth", "alpha", "tex_fg_fine", "depth_fine", "alpha_fine", "sdf", "tar_img", "tar_alpha", "input_mask", "img_in")},
+         loss=loss, **{"err_" + k: v for k, v in err.items()}, loss2=loss2, **{"err2_" + k: v for k, v in err2.items()})
 
     # ---- (ix) render_pifu_nerf pass order / pixel_shuffle (encoders replaced by the frame's feature maps) ----
     net.attach_geo_feat = lambda im, return_val=False: frame["feat_geo"]

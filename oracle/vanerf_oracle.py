@@ -425,6 +425,46 @@ def pixel_grid(width, height, level, stride_xy):
     return grids, index
 
 
+def train_window(msk, pick, out_h, out_w, width, height):
+    """Training branch of src/model.py:1172-1189: a out_h x out_w window of pixels centred on mask pixel number `pick` (the draw of
+    np.random.randint(0, n_mask_pixels), model.py:1182), clamped to [0, min(W-1, H-1)].  msk (H,W) bool -> grids (1,R,2) int64, index (1,R)."""
+    coords = torch.stack(torch.where(msk)[::-1], -1)
+    centre = coords[pick:pick + 1] if coords.shape[0] > 0 else torch.zeros((1, 2), dtype=torch.int64)
+    yg, xg = torch.meshgrid(torch.arange(0, out_h), torch.arange(0, out_w), indexing="ij")
+    grids = torch.stack([xg, yg], -1).view(-1, 2) + (centre - out_h // 2)
+    grids = grids.clamp(0, min(width - 1, height - 1))[None]
+    return grids, grids[..., 0] + grids[..., 1] * width
+
+
+def stratified(S, jitter):
+    """Coarse depth fractions of src/model.py:1222-1230 with uniform=False: jitter (B,R,S) in [0,1) = the draw of th.rand_like(z)."""
+    z = torch.linspace(0.0, 1.0, steps=S)[None, None, :].expand(*jitter.shape[:2], -1)
+    z_mid = 0.5 * (z[..., 1:] + z[..., :-1])
+    z_lower = torch.cat([z[..., :1], z_mid], -1)
+    z_upper = torch.cat([z_mid, z[..., -1:]], -1)
+    return z_lower + jitter * (z_upper - z_lower)
+
+
+def gt_gathers(index, out_h, out_w, tar_img=None, msk=None, fg_mask=None, img_in=None):
+    """GT gathers of src/model.py:1361-1418 at the pixel index of the pass (source-sized tensors are indexed with the TARGET index, as
+    the reference does): tar_img (B,3,H,W), msk (B,H,W), fg_mask (B,1,1,H,W) or (B,1,H,W), img_in (B,3,H,W)."""
+    out = {}
+
+    def g(t, ch):
+        flat = t.reshape(t.shape[0], ch, -1)
+        return torch.gather(flat, 2, index[:, None].expand(-1, ch, -1)).view(t.shape[0], ch, out_h, out_w)
+
+    if tar_img is not None:
+        out["tar_img"] = g(tar_img, 3)
+        if msk is not None:
+            out["tar_alpha"] = g(msk.reshape(msk.shape[0], 1, -1), 1).float()
+    if fg_mask is not None:
+        out["input_mask"] = g(fg_mask.reshape(fg_mask.shape[0], 1, *fg_mask.shape[-2:]), 1)
+    if img_in is not None:
+        out["img_in"] = g(img_in, 3)
+    return out
+
+
 def generate_rays(grids, cam_tar, bounds, znear, zfar):
     """src/model.py:1201-1220 -> cam_rays (B,R,3), cam_pos (B,1,3), znear_rays, zfar_rays (B,R,1), hit."""
     grids = grids.float()
@@ -454,9 +494,11 @@ def source_vert_xyz01(vert3d, cam):
 
 
 def batch_render(sd, frame, level, stride_xy, sample_per_ray_c=64, sample_per_ray_f=64, fine=True,
-                 sp_args=None, want=None, grids=None):
-    """Evaluation pass of VANeRF.batch_render_pifu_nerf (src/model.py:1102-1360) for B = V = 1, uniform=True.
-    The GT gathers and render_vis tail (1361-1420) do not feed RGB and are not restated.
+                 sp_args=None, want=None, grids=None, draws=None, tar_img=None, msk=None):
+    """VANeRF.batch_render_pifu_nerf (src/model.py:1102-1422) for B = V = 1.  draws=None: the evaluation pass (uniform=True).
+    draws = dict(jitter (1,R,Sc), u (1,R,Sf), noise_c (1,R*Sc,1), noise_f (1,R*(Sc+Sf),1), std): the training pass (uniform=False,
+    rand_noise_std=std) with the random numbers the reference draws at model.py:1229, 1443, 1156 (coarse, then fine) passed in.
+    tar_img / msk: adds the GT gathers of 1361-1418 (render_vis's images, 1377-1389, are discriminator input and not restated).
     Returns dict(tex_fg, depth, alpha, tex_fg_fine, depth_fine, alpha_fine, sdf, index, z, z_fine, ...)."""
     cam_in, cam_tar, targets = frame["cam_in"], frame["cam_tar"], frame["targets"]
     width = cam_tar.get("width", cam_in["width"])
@@ -473,14 +515,17 @@ def batch_render(sd, frame, level, stride_xy, sample_per_ray_c=64, sample_per_ra
         out_h, out_w = frame["out_hw"]
     cam_rays, cam_pos, znear_rays, zfar_rays, hit = generate_rays(grids, cam_tar, frame["bounds"], znear, zfar)
     S = sample_per_ray_c
-    z = torch.linspace(0.0, 1.0, steps=S)[None, None, :].expand(*znear_rays.shape[:2], -1)
+    if draws is None:
+        z = torch.linspace(0.0, 1.0, steps=S)[None, None, :].expand(*znear_rays.shape[:2], -1)
+    else:
+        z = stratified(S, draws["jitter"])
     z = znear_rays + (zfar_rays - znear_rays) * z
     vert3d = targets["vert_world"]
     face = targets["face_world"].long()
     vert_xy01, vert_z01 = source_vert_xyz01(vert3d, cam_in)
     img, fg_mask = frame["img_in"], frame["src_foreground_mask"]
 
-    def march(zs):
+    def march(zs, noise=None):
         S_ = zs.shape[-1]
         pts = (cam_pos[:, :, None] + cam_rays[:, :, None] * zs[..., None]).view(1, -1, 3)
         view = cam_rays[:, :, None, :].expand(-1, -1, S_, -1).reshape(1, -1, 3)
@@ -488,24 +533,29 @@ def batch_render(sd, frame, level, stride_xy, sample_per_ray_c=64, sample_per_ra
         w = {} if want is not None else None
         rgba, valid = query(sd, pts, cam_in, targets, frame["feat_geo"], frame["feat_tex"], vert_vis, q_vis, q_sdf,
                             frame["sp_data"], img, view, fg_mask, sp_args, w)
-        rgba = eval_func(sd, rgba, valid, cam_in["nml_scale"]).view(1, -1, S_, 5)
+        rgba = eval_func(sd, rgba, valid, cam_in["nml_scale"], noise=None if noise is None else noise * draws["std"]).view(1, -1, S_, 5)
         q_sdf = q_sdf.view(1, -1, S_, 1)
         color, depth, alpha, contrib, sdf = rgba2out(sd, rgba, zs, q_sdf)
         return dict(pts=pts, q_sdf=q_sdf, q_vis=q_vis, vert_vis=vert_vis, rgba=rgba, color=color, depth=depth, alpha=alpha,
                     contrib=contrib, sdf=sdf, inter=w)
 
-    c = march(z)
+    c = march(z, None if draws is None else draws.get("noise_c"))
     out = {"tex_fg": c["color"].view(1, out_h, out_w, 3).permute(0, 3, 1, 2), "depth": c["depth"].view(1, out_h, out_w),
            "alpha": c["alpha"].view(1, out_h, out_w), "index": index, "z": z, "hit": hit, "cam_rays": cam_rays,
            "cam_pos": cam_pos, "vert_vis": c["vert_vis"], "coarse": c}
     if fine:
         z_mid = 0.5 * (z[..., 1:] + z[..., :-1])
-        z_new = importance_sample(c["contrib"][..., 1:-1], z_mid, sample_per_ray_f, uniform=True)
+        if draws is None:
+            z_new = importance_sample(c["contrib"][..., 1:-1], z_mid, sample_per_ray_f, uniform=True)
+        else:
+            z_new = importance_sample(c["contrib"][..., 1:-1], z_mid, sample_per_ray_f, uniform=False, u=draws["u"])
         z_fine = torch.sort(torch.cat([z, z_new], -1), -1)[0]
-        f = march(z_fine)
+        f = march(z_fine, None if draws is None else draws.get("noise_f"))
         out.update({"tex_fg_fine": f["color"].view(1, out_h, out_w, 3).permute(0, 3, 1, 2),
                     "depth_fine": f["depth"].view(1, out_h, out_w), "alpha_fine": f["alpha"].view(1, out_h, out_w),
-                    "sdf": f["sdf"].view(1, out_h, out_w), "z_fine": z_fine, "fine": f})
+                    "sdf": f["sdf"].view(1, out_h, out_w), "z_fine": z_fine, "z_new": z_new, "fine": f})
+    if tar_img is not None:
+        out.update(gt_gathers(index, out_h, out_w, tar_img, msk, fg_mask, img))
     return out
 
 

@@ -14,6 +14,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--iters", type=int, default=5)
 ap.add_argument("--rows", type=int, default=512)
 ap.add_argument("--mode", type=int, default=0, help="0 = fp32 MFMA, 1 = split-bf16 x3")
+ap.add_argument("--order", type=int, default=1, help="1: work order from the validity partition (what render_pass does), 0: natural order")
 args = ap.parse_args()
 sd = synth.make_full_weights(0)
 frame = synth.make_frame(seed=11, tar_h=512, tar_w=334, orbit_deg=15.0)
@@ -24,13 +25,14 @@ w = R.PackedWeights(sd, mode=args.mode)
 rays = R.ray_setup(frame["cam_tar"], frame["bounds"], 0, 0, 1, 334, args.rows, 64, device="cuda")
 pts = R.sample_points(rays["rays_d"], rays["cam_pos"], rays["z"])
 q_sdf, q_vis, knn = R.mesh_query_accel(fdat.accel, fdat.verts3, fdat.faces, fdat.vert_vis, pts)
-out = R.query_samples(w, fdat, pts, q_sdf, q_vis, knn)
+order = R.query_order(fdat, pts) if args.order else None
+out = R.query_samples(w, fdat, pts, q_sdf, q_vis, knn, order=order)
 torch.cuda.synchronize()
 ts = []
 for _ in range(args.iters):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    out = R.query_samples(w, fdat, pts, q_sdf, q_vis, knn)
+    out = R.query_samples(w, fdat, pts, q_sdf, q_vis, knn, order=order)
     e1.record()
     torch.cuda.synchronize()
     ts.append(e0.elapsed_time(e1))

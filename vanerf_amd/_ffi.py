@@ -11,7 +11,7 @@ import torch  # noqa: F401  -- FIRST: torch ships its own libamdhip64; if libvan
 from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int64, c_uint, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libvanerf_hip.so")
+LIB_PATH = os.environ.get("VANERF_HIP_LIB") or os.path.join(_HERE, "lib", "libvanerf_hip.so")  # the override is for A/B runs of kernel builds (tools/)
 ABI_VERSION = 4
 NUM_LAYERS = 20
 

@@ -10,6 +10,10 @@ LIB = os.path.join(HERE, "lib", "libvanerf_hip.so")
 SOURCES = ["api.cpp", "weights_pack.cpp", "query_kernel.hip", "render_kernels.hip", "mesh_kernels.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-Wall", "-Wextra", "-Wno-unused-parameter"]
+# per-file flags.  query_kernel.hip: MFMA results are allocated in VGPRs (the chained layers read every accumulator element once with VALU
+# instructions; with the default AGPR form each read is a v_accvgpr_read first: 667 -> 95 per 32-sample group), and the SLP vectoriser
+# stays off (it packs adjacent f32 multiplies / adds into v_pk_* instructions, which cost more beside MFMAs than the scalar pairs).
+FILE_FLAGS = {"query_kernel.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-slp-vectorize"]}
 
 
 def _stale():
@@ -36,16 +40,17 @@ def _check_no_scratch(src, remarks):
         raise RuntimeError(f"{src}: kernels spill to scratch memory: {bad} (set VANERF_ALLOW_SCRATCH=1 to build anyway)")
 
 
-def build(force=False, verbose=False, extra=()):
+def build(force=False, verbose=False, extra=(), out=None):
+    """out: build an experiment variant into another file (tools/build_variants.py); the product library is LIB."""
     extra = tuple(extra) + tuple(os.environ.get("VANERF_HIPCC_FLAGS", "").split())
-    if not force and not _stale():
+    if out is None and not force and not _stale():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
     objs = []
     for src in SOURCES:
-        obj = os.path.join(HERE, "lib", src + ".o")
-        cmd = [hipcc, *FLAGS, *extra, "-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
+        obj = os.path.join(HERE, "lib", src + ".o") if out is None else out + "." + src + ".o"
+        cmd = [hipcc, *FLAGS, *FILE_FLAGS.get(src, []), *extra, "-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
         if src.endswith(".hip"):
             cmd[1:1] = ["-Rpass-analysis=kernel-resource-usage", "-fno-caret-diagnostics"]  # remarks without source snippets
         if verbose:
@@ -59,11 +64,11 @@ def build(force=False, verbose=False, extra=()):
             raise subprocess.CalledProcessError(res.returncode, cmd)
         _check_no_scratch(src, remarks)
         objs.append(obj)
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out or LIB, *objs]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
-    return LIB
+    return out or LIB
 
 
 if __name__ == "__main__":

@@ -234,10 +234,10 @@ __device__ __forceinline__ void run_layer_b(f32x16 (&acc)[NB], RingB<NB>& ring, 
                                             Pre&& pre = Pre{})
 {
     constexpr int D = RingDepthB<NB>::value, S = (T + 7) / 8;
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
-    // hi = bf16(x) (round to nearest even), lo = bf16(x - hi) for operand pair i of step s: 5 VALU -- v_cvt_pk, v_lshlrev, v_and, ONE
-    // v_pk_add_f32 for both subtractions, v_cvt_pk.  The empty asm keeps the packed hi opaque: without it the compiler re-converts
-    // each element on its own to feed the subtraction (7 per pair).
+    // hi = bf16(x) (round to nearest even), lo = bf16(x - hi) for operand pair i of step s: 6 VALU -- v_cvt_pk, v_lshlrev, v_and, two
+    // v_sub_f32, v_cvt_pk (no packed f32 math: a v_pk_add_f32 beside MFMAs costs more than the two scalar ops it replaces, and the file
+    // is built with -fno-slp-vectorize for the same reason).  The empty asm keeps the packed hi opaque: without it the compiler
+    // re-converts each element on its own to feed the subtraction (7 per pair).
     auto split_pair = [&](auto sc, auto ic, u32x4& bh, u32x4& bl) {
         constexpr int s = decltype(sc)::value, i = decltype(ic)::value, t0 = 8 * s + 2 * i;
         float x0 = 0.0f, x1 = 0.0f;
@@ -246,10 +246,7 @@ __device__ __forceinline__ void run_layer_b(f32x16 (&acc)[NB], RingB<NB>& ring, 
         unsigned hpk = pack_bf16(x0, x1);
         asm("" : "+v"(hpk));
         bh[i] = hpk;
-        const f32x2 xv = {x0, x1};
-        const f32x2 hv = {__uint_as_float(hpk << 16), __uint_as_float(hpk & 0xffff0000u)};
-        const f32x2 lo = xv - hv;
-        bl[i] = pack_bf16(lo.x, lo.y);
+        bl[i] = pack_bf16(x0 - __uint_as_float(hpk << 16), x1 - __uint_as_float(hpk & 0xffff0000u));
     };
     u32x4 bh, bl;
     pre(std::integral_constant<int, 0>{});
@@ -305,6 +302,11 @@ template <int NB> __device__ __forceinline__ void zero(f32x16 (&acc)[NB])
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[ob][r] = 0.0f;
 }
+
+// Barriers of the block's four waves.  block_barrier_lds: LDS writes before it are visible after it (s_waitcnt lgkmcnt(0) + s_barrier; NOT
+// __syncthreads(), whose workgroup-scope release also drains vmcnt -- the fragment prefetch and the stores of the previous group are in flight here).
+__device__ __forceinline__ void block_barrier_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// (More barriers inside a round were measured and lost: four rendezvous points in the layer stack cost 3.4 % -- 6.62 -> 6.84 ms.)
 
 // ---------------------------------------------------------------------------------------------
 // elementwise helpers
@@ -497,15 +499,6 @@ __global__ __launch_bounds__(BLOCK, MODE == 1 ? VANERF_WAVES_PER_SIMD_B : VANERF
     asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt0)::"memory");
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_prev)::"memory");
 #endif
-    // Dynamic work distribution: the two waves that share a SIMD do not progress at the same rate (the older one wins the
-    // issue arbitration), so a static split leaves half of the SIMDs idle for the last ~15 % of the launch.  Each wave
-    // claims one 32-sample group at a time from a device-scope counter; the next claim is issued a whole group ahead, so
-    // its latency is never exposed.  Every wave leaves the loop once the counter passes ngroups: the grid always drains.
-    auto claim = [&]() -> unsigned {
-        unsigned v = 0;
-        if (lane == 0) v = atomicAdd(P.queue, 1u);
-        return (unsigned)__builtin_amdgcn_readfirstlane((int)v);
-    };
     // split-bf16 kernel (one wave per SIMD, 512 registers): the lane half's 21 key points stay in registers for the whole launch
     // (63 VGPRs) -- per-group scalar loads of them exposed their latency 21 times per group with no second wave to hide it
     [[maybe_unused]] float kpx[PE_KPT_PER_HALF], kpy[PE_KPT_PER_HALF], kpz[PE_KPT_PER_HALF];
@@ -527,14 +520,24 @@ __global__ __launch_bounds__(BLOCK, MODE == 1 ? VANERF_WAVES_PER_SIMD_B : VANERF
         in.sdf = P.qsdf[sc]; in.knn = P.knn_in[sc]; in.vis = P.qvis[sc];
         return in;
     };
-    unsigned g_next = claim();
-    SampleIn in_next = fetch(g_next);
-    while (g_next < (unsigned)ngroups) {
-        const long long g = g_next;
+    // Work distribution.  A block claims FOUR consecutive 32-sample groups per round from a device-scope counter (wave w takes group
+    // base + w) and its waves meet at one barrier per round: they walk the weight stream together, so three of the four fetches of every
+    // fragment hit the CU's L1 instead of L2 (launch 7.6 -> 6.8 ms; with per-wave claims the waves drift apart and every wave streams the
+    // 660 KB from L2 on its own).  The claim for round r + 2 is issued at the start of round r (thread 0) and published through LDS at the
+    // start of round r + 1: no wave waits for the atomic.  The same barrier makes the "no valid sample" decision block-uniform, which is what
+    // allows barriers inside the layer stack.  Every block leaves the loop once the counter passes ngroups: the grid always drains.
+    __shared__ unsigned s_base[2];
+    __shared__ unsigned s_valid[2][WAVES_PER_BLOCK];
+    const unsigned wv = threadIdx.x >> 6;
+    unsigned pending = 0, par = 1;
+    if (threadIdx.x == 0) s_base[0] = atomicAdd(P.queue, (unsigned)WAVES_PER_BLOCK);
+    __syncthreads();
+    unsigned base_cur = s_base[0];
+    if (threadIdx.x == 0) pending = atomicAdd(P.queue, (unsigned)WAVES_PER_BLOCK);
+    SampleIn in_next = fetch(base_cur + wv);
+    while (base_cur < (unsigned)ngroups) {
+        const long long g = (long long)base_cur + wv; // a wave whose group lies beyond the last one runs with live == false: the block's barriers stay matched
         const SampleIn in = in_next;
-        g_next = claim();
-        in_next = fetch(g_next);
-        __builtin_amdgcn_sched_barrier(0x000F); // keep these loads here (the scheduler sinks loads to their first use)
         const long long s_raw = g * 32 + j;
         const bool live = s_raw < P.n;
         long long s = live ? s_raw : P.n - 1;
@@ -546,6 +549,17 @@ __global__ __launch_bounds__(BLOCK, MODE == 1 ? VANERF_WAVES_PER_SIMD_B : VANERF
         // ---- projection into the source view, validity mask, boundary weight (src/model.py:780-821) ----
         const Projected pr = project_and_mask(F, P.wm1[0], P.hm1[0], px, py, pz);
         const float x = pr.x, y = pr.y, zn = pr.zn, mask = pr.mask;
+        const bool wave_valid = __builtin_amdgcn_ballot_w64(mask > 0.0f) != 0ull;
+        if (lane == 0) s_valid[par][wv] = wave_valid ? 1u : 0u;
+        if (threadIdx.x == 0) s_base[par] = pending;
+        block_barrier_lds();
+        const unsigned base_next = (unsigned)__builtin_amdgcn_readfirstlane((int)s_base[par]);
+        const bool any_valid = __builtin_amdgcn_readfirstlane((int)(s_valid[par][0] | s_valid[par][1] | s_valid[par][2] | s_valid[par][3])) != 0;
+        par ^= 1u;
+        if (threadIdx.x == 0) pending = atomicAdd(P.queue, (unsigned)WAVES_PER_BLOCK);
+        in_next = fetch(base_next + wv);
+        base_cur = base_next;
+        __builtin_amdgcn_sched_barrier(0x000F); // keep these loads here (the scheduler sinks loads to their first use)
         const Bilin bi = bilin_setup(x, y, F.hi, F.wi, P.wm1[0], P.hm1[0]); // source-image taps (the same the mask used)
         float pw;
         {
@@ -595,7 +609,6 @@ __global__ __launch_bounds__(BLOCK, MODE == 1 ? VANERF_WAVES_PER_SIMD_B : VANERF
         // zero (0 * x), the density head is masked out by eval_func and only the colour branch (fed by the bias of
         // ibr_compress) survives.  When ALL 32 samples of the wave are such samples, GeoVisFusion, mlp_geo.layers1 and the head
         // (82 % of the MFMAs) are skipped -- same bits, wave-uniform branch.  With real foreground masks most samples are.
-        const bool any_valid = __builtin_amdgcn_ballot_w64(mask > 0.0f) != 0ull;
         if (any_valid) {
             auto r_at0 = ring_start_m<MODE, 1, 98, L_GEO_AT0_A>(W, lane);
             f32x16 g64[2], g8[1];
@@ -761,8 +774,8 @@ __global__ __launch_bounds__(BLOCK, MODE == 1 ? VANERF_WAVES_PER_SIMD_B : VANERF
             tex_gathers();
             zero<4>(pool);
             zero<1>(head);
-            if (lane == 0) ++short_groups;
         }
+        if (!wave_valid && lane == 0 && g < ngroups) ++short_groups; // counted by the wave's own samples (what bench.py prices), not by the block's path
         auto r_ibr = ring_start_m<MODE, 1, 65, L_IBR>(W, lane);
         STAMP(7); // pool + head
         // ---- ibr_compress_gfeat 128 -> 24 (src/model.py:921) ------------------------------------------------
