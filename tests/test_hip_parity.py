@@ -343,9 +343,15 @@ def test_query_samples_vs_oracle(R, sd_full, seed, half):
     print("query_samples max abs err [alpha, sdf, r, g, b]:", err.max(0)[0].tolist(), "alpha>0:", (ref[:, 0] > 0).float().mean().item())
     assert 0.05 < (ref[:, 0] > 0).float().mean() < 0.95 and 0.05 < valid.float().mean() < 0.999
     assert err.max() <= TOL
+    # Density.  sigma = sigmoid(-(alpha + sdf_mesh) / beta) / beta has slope up to 1 / (4 beta^2) = 25 in alpha at the default beta = 0.1 and
+    # reaches 1 / beta = 10: an absolute 1e-4 on sigma would demand 4e-6 on alpha, below what two fp32 summation orders of a 358-wide layer
+    # agree on (the fp32-MFMA kernel is within ~1e-5 of the oracle: summation order only).  Stated exception to the north star's
+    # "sigma within 1e-4 abs" (DESIGN.md section 5): sigma is held to 1e-4 RELATIVE TO ITS SCALE 1 / beta, i.e. |d sigma| * beta <= 1e-4;
+    # what the image sees is the compositing weight 1 - exp(-sigma dist), and the rendered RGB / alpha / depth are held to 1e-4 absolute.
     beta = 0.1
     sig_ref = torch.sigmoid(-(ref[:, 0]) / beta) / beta
     sig_got = torch.sigmoid(-(got[:, 0]) / beta) / beta
+    print("sigma: max abs err", (sig_ref - sig_got).abs().max().item(), "(scale 1/beta = 10)")
     assert (sig_ref - sig_got).abs().max() * beta <= TOL
 
 

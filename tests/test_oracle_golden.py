@@ -188,3 +188,41 @@ def test_render_full_stitch(golden, hot_weights):
             o = orc.batch_render(sd, fr, level, torch.tensor([[[j, i]]]), 8, 8)
             full[:, i::stride, j::stride] = o["tex_fg_fine"][0]
     close(full, g["tex_fg_fine"], 2e-6)
+
+
+def train_draws(g):
+    """The RNG draws the reference made in the recorded training pass (oracle/gen_golden.py, section viii-training)."""
+    return dict(jitter=g["jitter"], u=g["u"], noise_c=g["noise_c"], noise_f=g["noise_f"], std=0.01)
+
+
+def test_training_pass_with_recorded_draws(golden, hot_weights):
+    """SURVEY 8c (viii): one training-mode pass of the reference (16x16 window around a random mask pixel, src/model.py:1172-1189;
+    stratified depths 1226-1230; random importance draws 1443; rand_noise_std on both marches 1156) replayed by the oracle from the
+    recorded draws; plus the GT gathers of 1361-1418 with the reference's values."""
+    g = golden("pass_train_16x16_s16")
+    sd = dict(hot_weights)
+    sd.update(_texframe_weights(golden))
+    frame = _frame3()
+    S = int(g["S"])
+    grids, index = orc.train_window(g["msk_in"][0], int(g["pick"].reshape(-1)[0]), 16, 16, 64, 64)
+    assert index.min() >= 0 and grids.max() <= 63
+    frame["out_hw"] = (16, 16)
+    out = orc.batch_render(sd, frame, 5, None, S, S, grids=grids, draws=train_draws(g), tar_img=g["tar_img_in"], msk=g["msk_in"])
+    for k in ("tar_img", "tar_alpha", "input_mask", "img_in"):  # pure gathers at `index`: exact
+        assert torch.equal(out[k].float(), g[k].float()), k
+    assert 0.0 < out["tar_alpha"].mean() < 1.0  # the window straddles the mask edge
+    for k in ("tex_fg", "depth", "alpha"):
+        close(out[k], g[k], 2e-6)
+    for k in ("tex_fg_fine", "depth_fine", "alpha_fine", "sdf"):
+        close(out[k], g[k], 5e-6)
+    assert (out["z"][..., 1:] > out["z"][..., :-1]).all() and out["z"].std() > 0  # stratified, still ascending
+
+
+def test_gt_gathers_of_an_eval_pass(golden, hot_weights):
+    """src/model.py:1361-1418 on the 8x8 strided evaluation pass: target image / mask, source mask and source image gathered at `index`."""
+    g = golden("pass_8x8_s16")
+    frame = _frame3()
+    grids, index = orc.pixel_grid(64, 64, int(g["level"]), g["stride_xy"].long()[None, None])
+    got = orc.gt_gathers(index, 8, 8, g["gt_tar_img_in"], g["gt_msk_in"], frame["src_foreground_mask"], frame["img_in"])
+    for k in ("tar_img", "tar_alpha", "input_mask", "img_in"):
+        assert torch.equal(got[k].float(), g["gt_" + k].float()), k

@@ -1,6 +1,7 @@
 """Config surface of the hot path: the nested dict the reference builds from configs/vanerf.json (reference src/config.py:54-68).
 Only the keys the renderer reads are listed (SURVEY.md section 5 "Config / flags"); a reference config file loaded with json.load
-works unchanged -- extra keys (dataset, training, lambdas, Discriminator) are ignored by vanerf_amd.model.VANeRF."""
+works unchanged -- extra keys (dataset, training, Discriminator) are ignored by vanerf_amd.model.VANeRF; `lambdas` weights the loss that
+forward() returns (configs/vanerf.json:119-129)."""
 import copy
 
 _DEFAULT = {
@@ -16,6 +17,8 @@ _DEFAULT = {
             "mlp_tex_args": {"args": {"in_feat_ch": 32, "n_samples": 64}, "gcompress": {"in_ch": 128, "out_ch": 24}},
             "dr_level": 5,
             "dr_kwargs": {"fine": True, "uniform": False, "blur": 3, "rand_noise_std": 0.01, "sample_per_ray_c": 64, "sample_per_ray_f": 64},
+            "lambdas": {"lambda_l1_c": 1.0, "lambda_l1": 10.0, "lambda_vgg": 1.0, "lambda_l2": 0.0, "lambda_lp": 0.0, "lambda_ssim": 0.0,
+                        "lambda_colab": 0.0, "lambda_aux": 0.1, "lambda_ofs": 0.1},
         }
     }
 }

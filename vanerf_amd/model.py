@@ -11,7 +11,10 @@ What runs where
 
 Training: `forward()` in train mode under autograd returns the HIP values with the gradients of `vanerf_amd.torch_graph` -- the same
 networks re-evaluated with torch ops at the samples of the HIP pass ("fused HIP forward + PyTorch autograd backward", SURVEY.md
-section 8 row f-4, first stage; a fused HIP backward is not built).  Under no_grad / eval nothing of that runs.
+section 8 row f-4, first stage; a fused HIP backward is not built).  Under no_grad / eval nothing of that runs.  `forward()` returns the
+reference's `dict(loss, err_dict, out)`: the loss is `vanerf_amd.losses.compute_error` (src/utils.py:159-178) with `self.vgg_loss` as the
+perceptual term -- `None` unless the caller attaches one (the reference constructs a pretrained torchvision VGG19 there).
+A fresh module carries the reference's initial weights (`init_weights`, src/model.py:660-698; tests/golden/init_checksums.npz).
 """
 import copy
 import math
@@ -22,6 +25,7 @@ import torch.nn as nn
 import torch.nn.functional as thf
 
 from . import renderer as R
+from .losses import compute_error
 
 NUM_V = 779
 
@@ -158,10 +162,43 @@ class VANeRF(nn.Module):
         self.feat_tex = None
         self.kwargs = model_cfg
         self.disable_bg = True
+        # same three calls, same order as the reference's constructor (src/model.py:660-662)
+        self.init_weights(self)
+        self.init_weights(self.mlp_geo, "kaiming", nl="relu")
+        self.init_weights(self.mlp_tex, "kaiming", nl="leaky_relu")
+        self.vgg_loss = None  # perceptual term of forward()'s loss: a callable (pred, target) -> scalar, attached by the caller
         self.precision = model_cfg.get("mfma_precision", "fp32")  # "fp32" | "bf16x3" (renderer.PRECISIONS); not a reference key
         self._packed = None  # (version key, PackedWeights)
         self._frame_cache = None
         self._enc_cache = None  # (key, feat_geo, feat_tex, image)
+
+    @staticmethod
+    def init_weights(net, init_type="normal", gain=0.02, nl="relu"):
+        """src/model.py:660-698.  Every module re-seeds the global generator with 125 before its draw, so a layer's initial weight depends
+        only on its shape; weight-normed Linears keep PyTorch's default init (`m.weight` is their derived tensor, not a parameter), which is
+        why the constructor creates the fusion blocks and mlp_geo in the reference's order.  Not reproduced: the reference also sets
+        torch.backends.cudnn.deterministic = True here (a process-wide solver restriction, not a property of the weights)."""
+        def init_func(m):
+            torch.manual_seed(125)
+            classname = m.__class__.__name__
+            if hasattr(m, "weight") and (classname.find("Conv") != -1 or classname.find("Linear") != -1):
+                if init_type == "normal":
+                    nn.init.normal_(m.weight.data, 0.0, gain)
+                elif init_type == "xavier":
+                    nn.init.xavier_normal_(m.weight.data, gain=gain)
+                elif init_type == "kaiming":
+                    nn.init.kaiming_normal_(m.weight.data, a=0, mode="fan_in", nonlinearity=nl)
+                elif init_type == "orthogonal":
+                    nn.init.orthogonal_(m.weight.data, gain=gain)
+                else:
+                    raise NotImplementedError("initialization method [%s] is not implemented" % init_type)
+                if hasattr(m, "bias") and m.bias is not None:
+                    nn.init.constant_(m.bias.data, 0.0)
+            elif classname.find("BatchNorm2d") != -1:
+                nn.init.normal_(m.weight.data, 1.0, gain)
+                nn.init.constant_(m.bias.data, 0.0)
+
+        net.apply(init_func)
 
     # ---- image features (src/model.py:700-746) ---------------------------------------------------------------------
     def attach_im_feat(self, im, return_val=False):
@@ -231,8 +268,10 @@ class VANeRF(nn.Module):
         because render_pifu_nerf / render_novel_views call batch_render_pifu_nerf many times per source frame."""
         # identity AND version of every input; the tensors themselves are kept with the entry, so none of their addresses can be handed to a
         # different tensor while the entry is alive (an address alone would match a new batch that the allocator placed where the old one was)
-        deps = (img_in, feat_geo[0], feat_geo[1], feat_tex, targets["vert_world"], targets["face_world"], cam_in["KRT"], sp_data["kpt3d"], fg_mask)
-        key = tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in deps) + (tuple(p._version for p in self.tex_vis_fusion.parameters()),)
+        deps = (img_in, feat_geo[0], feat_geo[1], feat_tex, targets["vert_world"], targets["face_world"], cam_in["KRT"], sp_data["kpt3d"],
+                sp_data["extrin"], fg_mask)
+        scalars = tuple(float(cam_in[k]) for k in ("width", "height", "znear", "zfar", "nml_scale")) + tuple(sorted(self.kwargs["sp_args"].items()))
+        key = tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in deps) + (scalars, tuple(p._version for p in self.tex_vis_fusion.parameters()))
         if self._frame_cache is None or self._frame_cache[0] != key:
             sd = {"tex_vis_fusion." + k: v for k, v in self.tex_vis_fusion.state_dict().items()}
             fd = R.FrameData(sd, img_in, feat_geo, feat_tex, fg_mask, cam_in, targets, sp_data, self.kwargs["sp_args"])
@@ -297,6 +336,8 @@ class VANeRF(nn.Module):
         """src/model.py:1102-1422.  Same config keys (sample_per_ray_c/f, fine, uniform, rand_noise_std, src_foreground_mask, bounds, msk)."""
         batch_size = cam_tar["K"].shape[0]
         assert batch_size == 1 and n_views == 1, "val_batch_size = 1 and one source view (configs/vanerf.json:24; src/model.py:1044)"
+        if "transf" in cam_in or "transf" in cam_tar:  # the 2-D affine of src/model.py:783-785, 848-850, 1249-1251 (no shipped config sets it)
+            raise NotImplementedError("cam['transf'] is not folded into the HIP projection; fold it into KRT or drop the key")
         Sc = config.get("sample_per_ray_c", 64)
         Sf = config.get("sample_per_ray_f", 64)
         fine = config.get("fine", False)
@@ -324,11 +365,13 @@ class VANeRF(nn.Module):
         cam_t = dict(cam_tar, width=width, height=height, znear=cam_tar.get("znear", cam_in["znear"]), zfar=cam_tar.get("zfar", cam_in["zfar"]))
         fd = net.frame_data(img_in, cam_in, targets, feat_geo, feat_tex, sp_data, config["src_foreground_mask"])
         pixels = None
+        draws = config.get("_draws")  # tests: the random numbers of the pass handed in (pick, jitter, u, noise_c, noise_f) instead of drawn here
         if net.training and "msk" in config:  # 64x64 window around a random mask pixel, clamped (src/model.py:1172-1189)
             out_h, out_w = net.train_out_h, net.train_out_w
             msk = config["msk"][0].squeeze()
             coords = torch.stack(torch.where(msk)[::-1], -1)
-            centre = coords[np.random.randint(0, coords.shape[0], 1)] if coords.shape[0] > 0 else torch.zeros((1, 2), device=msk.device)
+            pick = np.random.randint(0, coords.shape[0], 1) if coords.shape[0] > 0 and draws is None else np.asarray(draws["pick"]).reshape(1) if draws else None
+            centre = coords[pick] if coords.shape[0] > 0 else torch.zeros((1, 2), device=msk.device)
             yg, xg = torch.meshgrid(torch.arange(0, out_h, device=dev), torch.arange(0, out_w, device=dev), indexing="ij")
             grids = torch.stack([xg, yg], -1).view(-1, 2) + (centre.to(dev) - out_h // 2)
             pixels = grids.clamp(0, min(width - 1, height - 1)).to(torch.int32).contiguous()
@@ -337,11 +380,15 @@ class VANeRF(nn.Module):
             out_w, out_h = width // st, height // st
             nx, ny, x0, y0, step = out_w, out_h, off[0], off[1], st
         Rn = out_w * out_h
-        jitter = None if uniform else torch.rand(Rn, Sc, device=dev)          # th.rand_like(z), src/model.py:1229
-        u = None if uniform else torch.rand(Rn, Sf, device=dev)                # th.rand(...), src/model.py:1443
+        if draws is not None and not uniform:
+            jitter, u = (draws[k].reshape(Rn, -1).to(dev, torch.float32).contiguous() for k in ("jitter", "u"))
+        else:
+            jitter = None if uniform else torch.rand(Rn, Sc, device=dev)          # th.rand_like(z), src/model.py:1229
+            u = None if uniform else torch.rand(Rn, Sf, device=dev)                # th.rand(...), src/model.py:1443
+        noise_draws = (draws["noise_c"], draws["noise_f"]) if draws is not None and noise_std > 0.0 else None
         want_graph = bool(config.get("_autograd", False))  # forward() under autograd: keep what vanerf_amd.torch_graph needs
         o = R.render_pass(net.packed_weights(), fd, cam_t, config["bounds"], x0, y0, step, nx, ny, Sc, Sf, fine=fine, jitter=jitter, u=u,
-                          noise_std=float(noise_std), pixels=pixels, debug=want_graph)
+                          noise_std=float(noise_std), pixels=pixels, debug=want_graph, noise_draws=noise_draws)
         if want_graph:
             net._last_pass = (o, fd, cam_in)
         out = {"tex_fg": o["color"].view(1, out_h, out_w, 3).permute(0, 3, 1, 2), "depth": o["depth"].view(1, out_h, out_w),
@@ -442,8 +489,8 @@ class VANeRF(nn.Module):
         return out
 
     def forward(self, im, cam, hand_type, targets, data, bbox, n_views=1, sp_data={}, dr_data=None, **kwargs):
-        """src/model.py:959-1024 (losses are the caller's: compute_error / VGG are outside the hot path).  Returns
-        dict(loss=None, err_dict={}, out={'nerf': out_nerf}) with the reference's out_nerf keys."""
+        """src/model.py:959-1024.  Returns dict(loss, err_dict, out={'nerf': out_nerf}) with the reference's out_nerf keys; the loss is
+        compute_error(inter_loss=None, out_nerf, vggloss=self.vgg_loss, lambdas=cfg lambdas) as at src/model.py:1023."""
         assert len(im.shape) == 4 and len(cam["KRT"].shape) == 3
         # Training under autograd ("fused HIP forward + PyTorch autograd backward", SURVEY.md section 8 row f-4, first stage): the values
         # come from the HIP pass, the gradients from vanerf_amd.torch_graph evaluated at the same samples (attach_autograd below).
@@ -457,7 +504,8 @@ class VANeRF(nn.Module):
             out_nerf = self.batch_render_pifu_nerf(self, dr_data["img"], dr_data["cam"], hand_type, targets, n_views, dr_data["cam_tar"], self.dr_level,
                                                    stride, dr_data["tar"], [f.detach() for f in feat_geo], feat_tex.detach(), None, sp_data,
                                                    dr_data.get("objcenter", None), msk=dr_data["msk"], src_foreground_mask=kwargs["src_foreground_mask"],
-                                                   bounds=kwargs["bounds"], _autograd=autograd, **dr_kwargs)
+                                                   bounds=kwargs["bounds"], _autograd=autograd, **{k: kwargs[k] for k in ("_draws",) if k in kwargs},
+                                                   **dr_kwargs)
         if autograd:
             self.attach_autograd(out_nerf, dr_data["img"], feat_geo, feat_tex, targets, sp_data, kwargs["src_foreground_mask"])
         if self.disable_bg:
@@ -465,20 +513,24 @@ class VANeRF(nn.Module):
         out_nerf["tex"] = out_nerf["tex_cal"] = out_nerf["tex_fg"]
         if "tex_fg_fine" in out_nerf:
             out_nerf["tex_fine"] = out_nerf["tex_cal_fine"] = out_nerf["tex_fg_fine"]
-        return dict(loss=None, err_dict={}, out={"nerf": out_nerf})
+        loss, err_dict = compute_error(inter_loss=None, out_nerf=out_nerf, vggloss=self.vgg_loss, lambdas=self.kwargs.get("lambdas", {}))
+        return dict(loss=loss, err_dict=err_dict, out={"nerf": out_nerf})
 
 
 def get_360cameras(headpose, focal, trans, sc_factor, im_w, im_h, znear, zfar, n_frames=90):
     """Orbit cameras of src/utils.py:63-134 (cv2.Rodrigues about the y axis written out; device follows `headpose`)."""
     device = headpose.device
+    # inverse of the head pose.  The reference writes `T_i[:3, :3] = T_i[:3, :3].t()` (src/utils.py:67): source and destination alias.  A
+    # device copy kernel reads every element before it writes (a true transpose, the intended inverse -- the reference's cameras live on the GPU);
+    # torch's sequential CPU copy would leave a symmetrised matrix instead.  Here the transpose is taken from `headpose` itself: same on every device.
     T_i = torch.eye(4, device=device)
-    T_i[:3, :4] = headpose[:3, :4]
-    T_i[:3, :3] = T_i[:3, :3].t()
-    T_i[:3, 3] = -T_i[:3, :3] @ T_i[:3, 3]
+    T_i[:3, :3] = headpose[:3, :3].t()
+    T_i[:3, 3] = -T_i[:3, :3] @ headpose[:3, 3]
     cams, theta0, theta1 = [], 0.0, 0.0
     for idx in range(n_frames):
-        c, s = math.cos(theta0), math.sin(theta0)
-        dR = torch.tensor([[c, 0.0, s], [0.0, 1.0, 0.0], [-s, 0.0, c]], dtype=torch.float32)  # Rodrigues((0, theta0, 0))
+        th32 = float(np.float32(theta0))  # the reference stores the angle in a float32 rotation vector before cv2.Rodrigues (src/utils.py:79-83)
+        c, s = math.cos(th32), math.sin(th32)
+        dR = torch.tensor([[c, 0.0, s], [0.0, 1.0, 0.0], [-s, 0.0, c]], dtype=torch.float32)  # Rodrigues((0, theta0, 0)), rounded to float32
         extrin_tar = torch.eye(4)
         intrin_tar = torch.eye(4)
         extrin_tar[:3, :3] = dR

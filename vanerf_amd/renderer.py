@@ -552,8 +552,15 @@ PARTITION_MIN_SAMPLES = 1 << 18
 
 def render_pass(weights, frame, cam_tar, bounds, x0, y0, step, nx, ny, sample_per_ray_c=64, sample_per_ray_f=64, fine=True,
                 jitter=None, u=None, noise_std=0.0, generator=None, debug=False, kernel_events=None, y_step=None, reuse_coarse=True,
-                pixels=None, y_block=1):
+                pixels=None, y_block=1, inject=None, noise_draws=None):
     """Returns flat per-ray tensors: color/depth/alpha (coarse), color_fine/depth_fine/alpha_fine/sdf (fine), index, z, z_fine.
+
+    noise_draws: optional (coarse, fine) standard-normal draws (flat, one per evaluated sample) used instead of fresh ones when
+    noise_std > 0 -- th.randn_like(rad) of src/model.py:1156 handed in (tests replay the reference's recorded draws).
+    inject: optional dict of device tensors that REPLACE what the ray kernels would produce, for parity tests that march the oracle's own
+    rays: "rays_d" (R,3), "cam_pos" (3,), "z" (R,Sc) and, for the fine march, "z_fine" (R,Sc+Sf) (then all Sc+Sf depths are evaluated: no
+    importance kernel, no coarse re-use).  Last-bit differences between torch-CPU and the HIP ray generator otherwise reach the discrete
+    decisions of the mesh query (closest face, inside test, visibility >= 0.1, 1-NN) on ~1e-5 of the samples.
 
     reuse_coarse: the fine composite needs the networks at the Sc coarse and the Sf new depths of every ray.  The reference
     evaluates all Sc+Sf again (src/model.py:1305-1345); the per-sample networks are pure functions of the position, so by
@@ -564,16 +571,25 @@ def render_pass(weights, frame, cam_tar, bounds, x0, y0, step, nx, ny, sample_pe
     rays = ray_setup(cam_tar, bounds, x0, y0, step, nx, ny, Sc, jitter=jitter, device=frame.verts3.device, y_step=y_step, pixels=pixels,
                      y_block=y_block)
     R = nx * ny
-    if noise_std > 0.0:
+    if inject is not None:
+        for k in ("rays_d", "cam_pos", "z"):
+            if k in inject:
+                if inject[k].shape != rays[k].shape or inject[k].dtype != torch.float32:
+                    raise ValueError(f"inject[{k!r}] must be float32 of shape {tuple(rays[k].shape)}")
+                rays[k] = inject[k].contiguous()
+    if noise_std > 0.0 or (inject is not None and "z_fine" in inject):
         reuse_coarse = False
+    if noise_draws is not None and (noise_draws[0].numel() != R * Sc or (fine and noise_draws[1].numel() != R * (Sc + Sf))):
+        raise ValueError("noise_draws: one draw per evaluated sample (R*Sc coarse, R*(Sc+Sf) fine)")
 
-    def evaluate(z):
+    def evaluate(z, draws=None):
         pts = sample_points(rays["rays_d"], rays["cam_pos"], z)
         grid = (nx, ny, z.shape[1]) if pixels is None else None
         q_sdf, q_vis, knn = mesh_query_accel(frame.accel, frame.verts3, frame.faces, frame.vert_vis, pts, grid=grid)
         noise = None
         if noise_std > 0.0:  # th.randn_like(rad) * rand_noise_std (src/model.py:1155-1156), drawn on the device
-            noise = torch.randn(pts.shape[0], device=pts.device, generator=generator) * noise_std
+            draws = torch.randn(pts.shape[0], device=pts.device, generator=generator) if draws is None else draws.reshape(-1).to(pts.device, torch.float32)
+            noise = (draws * noise_std).contiguous()
         if kernel_events is not None:  # HIP events around the dominant kernel, on the stream it is launched on
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -584,22 +600,27 @@ def render_pass(weights, frame, cam_tar, bounds, x0, y0, step, nx, ny, sample_pe
             kernel_events.append((e0, e1, pts.shape[0]))
         return dict(pts=pts, q_sdf=q_sdf.view(R, -1), q_vis=q_vis, knn=knn, noise=noise, rgba=rgba.view(R, -1, 5))
 
-    c = evaluate(rays["z"])
+    c = evaluate(rays["z"], None if noise_draws is None else noise_draws[0])
     c["color"], c["depth"], c["alpha"], c["contrib"], c["sdf"] = composite(c["rgba"], rays["z"], c["q_sdf"], weights.beta)
     out = {"color": c["color"], "depth": c["depth"], "alpha": c["alpha"], "index": rays["index"], "z": rays["z"], "hit": rays["hit"],
            "rays_d": rays["rays_d"], "cam_pos": rays["cam_pos"]}
     if debug:
         out["coarse"] = c
     if fine:
-        z_new, z_fine, src = importance_merge(c["contrib"], rays["z"], Sf, u=u)
+        if inject is not None and "z_fine" in inject:
+            z_new, z_fine, src = None, inject["z_fine"].contiguous(), None
+            if z_fine.shape != (R, Sc + Sf):
+                raise ValueError("inject['z_fine'] must have shape (R, Sc + Sf)")
+        else:
+            z_new, z_fine, src = importance_merge(c["contrib"], rays["z"], Sf, u=u)
         if reuse_coarse:
             f = evaluate(z_new)
             f["color"], f["depth"], f["alpha"], f["contrib"], f["sdf"] = composite_merged(c["rgba"], c["q_sdf"], f["rgba"], f["q_sdf"], src,
                                                                                           z_fine, weights.beta, want_contrib=debug)
         else:
-            f = evaluate(z_fine)
+            f = evaluate(z_fine, None if noise_draws is None else noise_draws[1])
             f["color"], f["depth"], f["alpha"], f["contrib"], f["sdf"] = composite(f["rgba"], z_fine, f["q_sdf"], weights.beta, want_contrib=debug)
-        out.update({"color_fine": f["color"], "depth_fine": f["depth"], "alpha_fine": f["alpha"], "sdf": f["sdf"], "z_fine": z_fine})
+        out.update({"color_fine": f["color"], "depth_fine": f["depth"], "alpha_fine": f["alpha"], "sdf": f["sdf"], "z_fine": z_fine, "z_new": z_new})
         if debug:
             out["fine"] = f
             out["fine_src"] = src if reuse_coarse else None
