@@ -118,6 +118,34 @@ def test_mesh_query_accel_equals_brute_force(R):
         assert 0.02 < (s0 < 0).float().mean() < 0.9
 
 
+@pytest.mark.parametrize("seed,hw,tar_w,orbit,S,step", [(11, 512, 334, 15.0, 24, 2), (5, 256, 256, 70.0, 32, 2), (3, 64, 64, 8.0, 16, 1)])
+def test_mesh_query_tile_search_equals_brute_force(R, seed, hw, tar_w, orbit, S, step):
+    """The tile searches of vanerf_mesh_query_accel (ray-grid hint: a wave = one depth of an 8x8 pixel tile, candidates found for the tile's
+    centre by the whole wave, then evaluated per lane) on the samples of real ray grids -- fine tiles of the benchmark camera, a large view
+    change, and a coarse 64x64 view whose tiles are centimetres wide (partly the per-lane fall-back): bit-identical to the exhaustive scan
+    in signed distance, visibility flag, closest face and 1-NN vertex."""
+    frame = _frame(seed, hw, orbit, tar_w=tar_w)
+    verts = dev(frame["targets"]["vert_world"][0].contiguous())
+    faces = dev(frame["targets"]["face_world"][0].to(torch.int32))
+    nx, ny = tar_w // step, hw // step
+    rays = R.ray_setup(frame["cam_tar"], frame["bounds"], 0, 0, step, nx, ny, S, device="cuda")
+    pts = R.sample_points(rays["rays_d"], rays["cam_pos"], rays["z"])
+    g = torch.Generator().manual_seed(seed)
+    vv = dev((torch.rand(verts.shape[0], generator=g) > 0.5).float())
+    accel = R.MeshAccel(verts, faces)
+    s1, v1, f1, k1 = R.mesh_query_accel(accel, verts, faces, vv, pts, want_face=True, grid=(nx, ny, S))
+    # the exhaustive kernels on a subset (they cost 3108 exact distances per point): every 5th ray, all of its depths
+    sel = (torch.arange(0, nx * ny, 5, device="cuda")[:, None] * S + torch.arange(S, device="cuda")[None]).reshape(-1)
+    sub = pts[sel].contiguous()
+    s0, v0, f0 = R.mesh_query(verts, faces, vv, sub, want_face=True)
+    v4 = torch.cat([verts, torch.zeros(verts.shape[0], 1, device="cuda")], 1).contiguous()
+    assert torch.equal(s0, s1[sel]) and torch.equal(v0, v1[sel]) and torch.equal(f0, f1[sel]) and torch.equal(R.knn1(v4, sub), k1[sel])
+    # and the whole batch against the per-lane search (no hint)
+    s2, v2, f2, k2 = R.mesh_query_accel(accel, verts, faces, vv, pts, want_face=True)
+    assert torch.equal(s1, s2) and torch.equal(v1, v2) and torch.equal(f1, f2) and torch.equal(k1, k2)
+    assert 0.001 < (s1 < 0).float().mean() < 0.9 and rays["hit"].float().mean() > 0.05
+
+
 def test_ray_setup(R):
     for seed, hw, tw, step, off in ((3, 64, 64, 8, (3, 5)), (11, 512, 334, 2, (1, 0))):
         frame = _frame(seed, hw, 15.0, tar_w=tw)

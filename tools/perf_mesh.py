@@ -28,7 +28,7 @@ for grid in ((334, 512, 64), None):
 if "--phases" in sys.argv:  # needs VANERF_HIPCC_FLAGS=-DVANERF_MESH_PHASES
     import ctypes
     from vanerf_amd._ffi import lib
-    buf = (ctypes.c_uint64 * 8)()
+    buf = (ctypes.c_uint64 * 16)()
     lib.vanerf_debug_mesh_phases.restype = ctypes.c_int
     lib.vanerf_debug_mesh_phases(buf, 1)
     R.mesh_query_accel(fdat.accel, fdat.verts3, fdat.faces, fdat.vert_vis, pts, grid=(334, 512, 64)); torch.cuda.synchronize()
@@ -37,4 +37,6 @@ if "--phases" in sys.argv:  # needs VANERF_HIPCC_FLAGS=-DVANERF_MESH_PHASES
     for name, v in zip(["point load", "1-NN vertex", "closest face", "inside test", "visibility + stores"], buf):
         print(f"  {name:20s} {100.0 * v / tot:5.1f} %  {v / (pts.shape[0] / 64):9.0f} cycles per 64 points")
     nw = pts.shape[0] / 64
-    print(f"  per wave of 64 points: {buf[5] / nw:.1f} clusters pass the wave-level test, {buf[6] / nw:.1f} are opened by some lane (16 bound tests each), {buf[7] / nw:.1f} exact evaluations")
+    print(f"  per wave of 64 points (per-lane search): {buf[5] / nw:.1f} clusters pass the wave-level test, {buf[6] / nw:.1f} are opened by some lane, {buf[7] / nw:.1f} exact evaluations")
+    nt = max(1, buf[8])
+    print(f"  closest face: {buf[8]} waves by the tile search ({buf[10] / nt:.0f} cycles each up to here, {buf[12] / nt:.1f} clusters listed, {buf[11] / nt:.1f} per-lane evaluations), {buf[9]} waves by the per-lane search")

@@ -17,11 +17,11 @@ __device__ __forceinline__ f3 sub3(f3 a, f3 b) { return {a.x - b.x, a.y - b.y, a
 __device__ __forceinline__ float dot3(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
 __device__ __forceinline__ f3 madd3(f3 a, f3 d, float t) { return {a.x + d.x * t, a.y + d.y * t, a.z + d.z * t}; }
 
-__device__ __forceinline__ float point_tri_dist2(f3 p, f3 a, f3 b, f3 c)
+// squared distance from p to triangle (a, b, c); q = the closest point of the triangle
+__device__ __forceinline__ float point_tri_dist2_q(f3 p, f3 a, f3 b, f3 c, f3& q)
 {
     const f3 ab = sub3(b, a), ac = sub3(c, a), ap = sub3(p, a);
     const float d1 = dot3(ab, ap), d2 = dot3(ac, ap);
-    f3 q;
     if (d1 <= 0.0f && d2 <= 0.0f) {
         q = a;
     } else {
@@ -61,6 +61,12 @@ __device__ __forceinline__ float point_tri_dist2(f3 p, f3 a, f3 b, f3 c)
     }
     const f3 r = sub3(p, q);
     return dot3(r, r);
+}
+
+__device__ __forceinline__ float point_tri_dist2(f3 p, f3 a, f3 b, f3 c)
+{
+    f3 q;
+    return point_tri_dist2_q(p, a, b, c, q);
 }
 
 // canonical (index-ordered) edge function in the (y,z) plane, see oracle/mesh_oracle.c:edge_side
@@ -241,10 +247,18 @@ constexpr int CL = VANERF_MA_CL; // triangles (and vertices) per cluster.  Measu
 constexpr int MA_BLOCK = VANERF_MA_BLOCK;
 constexpr int MA_MAX_CLUSTERS = 4096;
 constexpr int MA_MAX_VCLUSTERS = 1024;
+// tile searches (below): clusters a wave's candidate list can hold, and the 64-candidate rounds that makes
+#ifndef VANERF_TL_LIST
+#define VANERF_TL_LIST 128 // measured on the benchmark view: 64 -> 4.04 ms, 128 -> 3.46, 192 -> 4.43, 256 -> 4.18
+#endif
+constexpr int TL_LIST = VANERF_TL_LIST;
+constexpr int TL_IT = TL_LIST * CL / 64;
+constexpr int TL_CAND = 40; // triangles (9 floats + original index, padded to 12) a wave's candidate table holds
+static_assert(TL_LIST * CL % 64 == 0 && MA_MAX_CLUSTERS <= 65536, "candidate lists hold 16-bit cluster ids in whole rounds of 64");
 
 // Diagnostic build only (-DVANERF_MESH_PHASES): s_memtime deltas per phase, summed over waves (tools/perf_mesh.py --phases)
 #ifdef VANERF_MESH_PHASES
-__device__ unsigned long long g_ma_phase[8];
+__device__ unsigned long long g_ma_phase[16];
 #define MPH(k) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ph[k] += t_ - tprev; tprev = t_; } while (0)
 #else
 #define MPH(k) do { } while (0)
@@ -266,6 +280,8 @@ __global__ __launch_bounds__(MA_BLOCK) void mesh_query_accel_kernel(const Vanerf
 {
     // dynamic LDS: [nvc*16] sorted vertices (float4) | [nvc][6] vertex-cluster boxes | [nc][6] triangle-cluster boxes
     extern __shared__ float4 s_dyn[];
+    __shared__ unsigned short s_list[MA_BLOCK / 64][TL_LIST]; // per-wave candidate lists of the tile searches
+    __shared__ __attribute__((aligned(16))) float s_cand[MA_BLOCK / 64][TL_CAND][12];
     float4* s_vs = s_dyn;
     float* s_vbox = reinterpret_cast<float*>(s_vs + A.nvc * CL);
     float* s_box = s_vbox + A.nvc * 6;
@@ -282,7 +298,7 @@ __global__ __launch_bounds__(MA_BLOCK) void mesh_query_accel_kernel(const Vanerf
     const int ntx = (gnx + 7) >> 3, nty = (gny + 7) >> 3;
     const long long nwork = gnx > 0 ? (long long)ntx * nty * gS : (n + 63) >> 6;
 #ifdef VANERF_MESH_PHASES
-    unsigned long long ph[8] = {}, tprev = __builtin_amdgcn_s_memtime();
+    unsigned long long ph[16] = {}, tprev = __builtin_amdgcn_s_memtime();
 #endif
     for (long long w = wave0; w < nwork; w += nwaves) {
         // every lane keeps a point (the searches below are wave-cooperative): a lane beyond the grid border / the end of the batch
@@ -325,8 +341,124 @@ __global__ __launch_bounds__(MA_BLOCK) void mesh_query_accel_kernel(const Vanerf
             for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m));
             return v;
         };
+        auto wave_min = [&](float v) {
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) v = fminf(v, __shfl_xor(v, m));
+            return v;
+        };
+        // ---- Tile searches.  With the ray-grid hint the 64 points of a wave lie within a few millimetres of each other -- less than a
+        //      triangle -- so the wave first answers the query for ONE point, the centre tc of its tile, with the lanes working on 64
+        //      CANDIDATES at a time (clusters, then the triangles / vertices of the surviving clusters), and only then every lane evaluates,
+        //      for its own point, the few candidates that can still matter.  Which ones can (rho = max |p - tc| over the wave, D = the
+        //      minimum at tc, attained on t_D at the point q_D, u_t = the unit vector from t's closest point to tc, w = p - tc):
+        //        (i)  distances are 1-Lipschitz:  d(p, t*) <= d(p, t_D) <= D + rho  and  d(tc, t*) <= d(p, t*) + rho, so the minimum t* of
+        //             a lane has  d(tc, t*) - D <= 2 rho;
+        //        (ii) the distance to a convex set is convex:  d(p, t) >= d(tc, t) + u_t.w,  while  d(p, t_D) <= |p - q_D| <=
+        //             D + u_D.w + |w|^2 / (2 D);  so t can beat t_D at some p of the tile only if
+        //             d(tc, t) - D <= |u_t - u_D| rho + rho^2 / (2 D).
+        //      (ii) is what keeps tiles centimetres from the mesh cheap: there dozens of triangles lie within 2 rho of the minimum, but
+        //      their u_t are nearly parallel.  `slack` adds 10 um on top of 2 rho and (ii) carries 20 um, two orders of magnitude above the
+        //      fp32 rounding of a computed distance at these coordinates (~0.1 um), so every candidate whose COMPUTED distance could win or
+        //      tie survives: the per-lane arg-min (ties to the lowest original index) is the exhaustive scan's, bit for bit.  A tile too
+        //      large for the candidate tables (rays on the silhouette of the bounding box, samples decimetres from the mesh, launches
+        //      without the hint) falls back to the per-lane search below.
+        //      Measured and dropped: taking the seed cluster's best triangle as the reference of (ii) from the start, with a cylinder
+        //      around each cluster as its lower bound (no search for D first): looser at every level -- 106 instead of 62 listed clusters,
+        //      19 instead of 13 per-lane evaluations, 44 % instead of 71 % of the waves within the tables; 4.6 ms against 3.4.
+        unsigned short* const my_list = s_list[threadIdx.x >> 6];
+        const f3 tc = {0.5f * (tlo[0] + thi[0]), 0.5f * (tlo[1] + thi[1]), 0.5f * (tlo[2] + thi[2])};
+        float slack;
+        {
+            const float ex = p.x - tc.x, ey = p.y - tc.y, ez = p.z - tc.z;
+            slack = 2.0f * sqrtf(wave_max((ex * ex + ey * ey) + ez * ez)) * (1.0f + 1e-5f) + 1e-5f;
+        }
+        const float rho = 0.5f * slack;
+        const bool try_tile = gnx > 0 && slack < 0.05f; // (a NaN slack compares false)
+        auto sq_plus = [&](float d2) { const float r = sqrtf(d2) + slack; return (r * r) * (1.0f + 1e-4f) + 1e-12f; }; // (i), squared
+        // (i) and (ii) for a candidate at distance d from tc whose unit vector differs from u_R by du (R = the reference's distance)
+        auto may_win = [&](float d, float R, float du, bool have_uR) {
+            const float lim = (have_uR && R > 1e-4f) ? fminf(slack, du * rho * (1.0f + 1e-4f) + (rho * rho) / (2.0f * R) * (1.0f + 1e-4f) + 2e-5f) : slack;
+            return d - R <= lim;
+        };
+        auto mbcnt = [&](unsigned long long m) { return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u)); };
+        // appends the clusters of [0, ncl) whose box is within thr (squared) of tc to the wave's list; returns how many there are
+        auto collect = [&](const float* boxes, int ncl, float thr) {
+            int ns = 0;
+            for (int c0 = 0; c0 < ncl; c0 += 64) {
+                const int cl_ = c0 + lane;
+                const bool keep = cl_ < ncl && box_dist2(tc, boxes + 6 * min(cl_, ncl - 1)) <= thr;
+                const unsigned long long m = __ballot(keep);
+                const int pos = ns + mbcnt(m);
+                if (keep && pos < TL_LIST) my_list[pos] = (unsigned short)cl_;
+                ns += __builtin_popcountll(m);
+            }
+            __builtin_amdgcn_wave_barrier();
+            return ns;
+        };
         float vb = INFINITY;
         int vi = 0x7fffffff;
+        auto knn_tile = [&](int cm) -> bool { // cm: the vertex cluster nearest to tc
+            float U = INFINITY;
+            if (lane < CL) {
+                const float4 v = s_vs[cm * CL + lane];
+                const float dx = tc.x - v.x, dy = tc.y - v.y, dz = tc.z - v.z;
+                U = (dx * dx + dy * dy) + dz * dz;
+            }
+            U = wave_min(U);
+            const int ns = collect(s_vbox, A.nvc, sq_plus(U));
+            if (ns > TL_LIST) return false;
+            const int nt = ns * CL;
+            float d_it[TL_IT];
+            int s_it[TL_IT];
+#pragma unroll
+            for (int it = 0; it < TL_IT; ++it) {
+                d_it[it] = INFINITY; s_it[it] = 0;
+                const int j = it * 64 + lane;
+                if (it * 64 < nt && j < nt) {
+                    const int slot = (int)my_list[j / CL] * CL + j % CL;
+                    const float4 v = s_vs[slot];
+                    const float dx = tc.x - v.x, dy = tc.y - v.y, dz = tc.z - v.z;
+                    d_it[it] = (dx * dx + dy * dy) + dz * dz;
+                    s_it[it] = slot;
+                }
+                U = fminf(U, d_it[it]);
+            }
+            const float D2 = wave_min(U), Tf = sq_plus(D2), D = sqrtf(D2);
+            // reference: a vertex that attains the minimum at tc (always found: the seed cluster is on the list; if it ever were not, (i) alone decides)
+            int slotD = 0;
+            bool have = false;
+#pragma unroll
+            for (int it = TL_IT - 1; it >= 0; --it) {
+                const unsigned long long m = (it * 64 < nt) ? __ballot(d_it[it] == D2) : 0ull;
+                if (m) { slotD = __builtin_amdgcn_readlane(s_it[it], __builtin_ctzll(m)); have = true; }
+            }
+            const float4 vD = s_vs[slotD];
+            const float invD = D > 1e-4f ? 1.0f / D : 0.0f;
+            const f3 uD = {(tc.x - vD.x) * invD, (tc.y - vD.y) * invD, (tc.z - vD.z) * invD};
+#pragma unroll
+            for (int it = 0; it < TL_IT; ++it) {
+                if (it * 64 < nt) {
+                    bool cand = d_it[it] <= Tf;
+                    if (cand) {
+                        const float4 v = s_vs[s_it[it]];
+                        const float d = sqrtf(d_it[it]), inv = 1.0f / fmaxf(d, 1e-20f);
+                        const float ex = (tc.x - v.x) * inv - uD.x, ey = (tc.y - v.y) * inv - uD.y, ez = (tc.z - v.z) * inv - uD.z;
+                        cand = may_win(d, D, sqrtf((ex * ex + ey * ey) + ez * ez), have);
+                    }
+                    unsigned long long m = __ballot(cand);
+                    while (m) {
+                        const int src = __builtin_ctzll(m);
+                        m &= m - 1;
+                        const float4 v = s_vs[__builtin_amdgcn_readlane(s_it[it], src)];
+                        const float dx = p.x - v.x, dy = p.y - v.y, dz = p.z - v.z;
+                        const float d = (dx * dx + dy * dy) + dz * dz;
+                        const int oi = __float_as_int(v.w);
+                        if (d < vb || (d == vb && oi < vi)) { vb = d; vi = oi; }
+                    }
+                }
+            }
+            return true;
+        };
         {
             auto eval_v = [&](int c) {
                 for (int k = 0; k < CL; ++k) {
@@ -338,7 +470,6 @@ __global__ __launch_bounds__(MA_BLOCK) void mesh_query_accel_kernel(const Vanerf
                 }
             };
             // seed: the vertex cluster nearest to the centre of T, evaluated by every lane
-            const f3 tc = {0.5f * (tlo[0] + thi[0]), 0.5f * (tlo[1] + thi[1]), 0.5f * (tlo[2] + thi[2])};
             float smin = INFINITY;
             int cm = 0;
             for (int c = lane; c < A.nvc; c += 64) {
@@ -351,16 +482,20 @@ __global__ __launch_bounds__(MA_BLOCK) void mesh_query_accel_kernel(const Vanerf
                 const int oc = __shfl_xor(cm, m);
                 if (o < smin || (o == smin && oc < cm)) { smin = o; cm = oc; }
             }
-            eval_v(cm);
-            const float capw = wave_max(vb) * (1.0f + 1e-4f) + 1e-12f;
-            for (int c0 = 0; c0 < A.nvc; c0 += 64) {
-                const int cl_ = c0 + lane;
-                unsigned long long m = __ballot(cl_ < A.nvc && cl_ != cm && tile_dist2(s_vbox + 6 * min(cl_, A.nvc - 1)) <= capw);
-                while (m) {
-                    const int c = c0 + __builtin_ctzll(m);
-                    m &= m - 1;
-                    if (box_dist2(p, s_vbox + 6 * c) > vb * (1.0f + 1e-4f) + 1e-12f) continue;
-                    eval_v(c);
+            cm = __builtin_amdgcn_readfirstlane(cm);
+            if (!(try_tile && knn_tile(cm))) { // per-lane search: every lane prunes against its own point and bound
+                vb = INFINITY; vi = 0x7fffffff;
+                eval_v(cm);
+                const float capw = wave_max(vb) * (1.0f + 1e-4f) + 1e-12f;
+                for (int c0 = 0; c0 < A.nvc; c0 += 64) {
+                    const int cl_ = c0 + lane;
+                    unsigned long long m = __ballot(cl_ < A.nvc && cl_ != cm && tile_dist2(s_vbox + 6 * min(cl_, A.nvc - 1)) <= capw);
+                    while (m) {
+                        const int c = c0 + __builtin_ctzll(m);
+                        m &= m - 1;
+                        if (box_dist2(p, s_vbox + 6 * c) > vb * (1.0f + 1e-4f) + 1e-12f) continue;
+                        eval_v(c);
+                    }
                 }
             }
             if (vi == 0x7fffffff) vi = 0; // a NaN point compares false with everything: index 0, like the exhaustive scan
@@ -412,8 +547,98 @@ __global__ __launch_bounds__(MA_BLOCK) void mesh_query_accel_kernel(const Vanerf
                 if (d < best || (d == best && of < bf)) { best = d; bf = of; }
             }
         };
+        auto face_tile = [&](int cseed) -> bool { // cseed: the triangle cluster nearest to tc
+            struct Tri { f3 a, b, c; };
+            auto load_tri = [&](int t) {
+                const float* r = A.tri + (size_t)t * 9;
+                return Tri{{r[0], r[1], r[2]}, {r[3], r[4], r[5]}, {r[6], r[7], r[8]}};
+            };
+            float U = INFINITY;
+            if (lane < CL) { const Tri T = load_tri(cseed * CL + lane); U = point_tri_dist2(tc, T.a, T.b, T.c); }
+            U = wave_min(U);
+            const float thr = sq_plus(U);
+            const int ns = collect(s_box, A.nc, thr);
+            if (ns > TL_LIST) return false;
+#ifdef VANERF_MESH_PHASES
+            if (lane == 0) ph[12] += ns; // clusters on the list
+#endif
+            const int nt = ns * CL;
+            // round `it`: lane l looks at triangle number 64 it + l of the listed clusters.  First the disc bounds of all rounds (their loads
+            // are independent and overlap), then the exact distances at tc of the triangles whose bound is within the seed's threshold.
+            float d_it[TL_IT];
+            int t_it[TL_IT];
+#pragma unroll
+            for (int it = 0; it < TL_IT; ++it) {
+                d_it[it] = INFINITY; t_it[it] = 0;
+                const int j = it * 64 + lane;
+                if (it * 64 < nt && j < nt) {
+                    const int t = (int)my_list[j / CL] * CL + j % CL;
+                    t_it[it] = t;
+                    const float4 sp = reinterpret_cast<const float4*>(A.sphere)[t], tn = reinterpret_cast<const float4*>(A.tnorm)[t];
+                    d_it[it] = disc_lb2(sp, tn, tc) <= thr ? 0.0f : INFINITY; // 0 = "evaluate me"
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < TL_IT; ++it)
+                if (it * 64 < nt && d_it[it] == 0.0f) { const Tri T = load_tri(t_it[it]); d_it[it] = point_tri_dist2(tc, T.a, T.b, T.c); }
+#pragma unroll
+            for (int it = 0; it < TL_IT; ++it) U = fminf(U, d_it[it]);
+            const float D2 = wave_min(U), Tf = sq_plus(D2), D = sqrtf(D2);
+            // reference: (one of) the triangle(s) that attain the minimum at tc, with its closest point q_D
+            int tD = cseed * CL;
+            bool have = false;
+#pragma unroll
+            for (int it = TL_IT - 1; it >= 0; --it) {
+                const unsigned long long m = (it * 64 < nt) ? __ballot(d_it[it] == D2) : 0ull;
+                if (m) { tD = __builtin_amdgcn_readlane(t_it[it], __builtin_ctzll(m)); have = true; }
+            }
+            f3 qD;
+            { const Tri T = load_tri(tD); point_tri_dist2_q(tc, T.a, T.b, T.c, qD); }
+            const float invD = D > 1e-4f ? 1.0f / D : 0.0f;
+            const f3 uD = {(tc.x - qD.x) * invD, (tc.y - qD.y) * invD, (tc.z - qD.z) * invD};
+            // the triangles that pass (i) get a second look (their closest point, for (ii)); those that pass both go to the wave's LDS
+            // candidate table, from where every lane evaluates them for its own point
+            float* const ctab = s_cand[threadIdx.x >> 6][0];
+            int K = 0;
+#pragma unroll
+            for (int it = 0; it < TL_IT; ++it) {
+                if (it * 64 < nt && __ballot(d_it[it] <= Tf)) {
+                    bool cand = d_it[it] <= Tf;
+                    Tri T = {};
+                    if (cand) {
+                        T = load_tri(t_it[it]);
+                        f3 qt;
+                        point_tri_dist2_q(tc, T.a, T.b, T.c, qt);
+                        const float d = sqrtf(d_it[it]), inv = 1.0f / fmaxf(d, 1e-20f);
+                        const float ex = (tc.x - qt.x) * inv - uD.x, ey = (tc.y - qt.y) * inv - uD.y, ez = (tc.z - qt.z) * inv - uD.z;
+                        cand = may_win(d, D, sqrtf((ex * ex + ey * ey) + ez * ez), have);
+                    }
+                    const unsigned long long m = __ballot(cand);
+                    const int pos = K + mbcnt(m);
+                    if (cand && pos < TL_CAND) {
+                        float* e = ctab + pos * 12;
+                        e[0] = T.a.x; e[1] = T.a.y; e[2] = T.a.z; e[3] = T.b.x; e[4] = T.b.y; e[5] = T.b.z; e[6] = T.c.x; e[7] = T.c.y; e[8] = T.c.z;
+                        e[9] = __int_as_float(A.orig[t_it[it]]);
+                    }
+                    K += __builtin_popcountll(m);
+                }
+            }
+            if (K > TL_CAND) return false;
+            __builtin_amdgcn_wave_barrier();
+#ifdef VANERF_MESH_PHASES
+            if (lane == 0) ph[11] += K; // per-lane evaluations of the tile search
+#endif
+            for (int k = 0; k < K; ++k) {
+                const float4 e0 = reinterpret_cast<const float4*>(ctab + k * 12)[0], e1 = reinterpret_cast<const float4*>(ctab + k * 12)[1],
+                             e2 = reinterpret_cast<const float4*>(ctab + k * 12)[2];
+                const f3 a = {e0.x, e0.y, e0.z}, b = {e0.w, e1.x, e1.y}, c3 = {e1.z, e1.w, e2.x};
+                const float d = point_tri_dist2(p, a, b, c3);
+                const int of = __float_as_int(e2.y);
+                if (d < best || (d == best && of < bf)) { best = d; bf = of; }
+            }
+            return true;
+        };
         // (1) seed: the cluster nearest to the centre of T, all of its triangles, so that every lane holds a bound close to its answer
-        const f3 tc = {0.5f * (tlo[0] + thi[0]), 0.5f * (tlo[1] + thi[1]), 0.5f * (tlo[2] + thi[2])};
         int cseed = 0;
         {
             float smin = INFINITY;
@@ -428,11 +653,15 @@ __global__ __launch_bounds__(MA_BLOCK) void mesh_query_accel_kernel(const Vanerf
                 if (o < smin || (o == smin && oc < cseed)) { smin = o; cseed = oc; }
             }
             cseed = __builtin_amdgcn_readfirstlane(cseed);
-            eval_cluster(cseed);
         }
+        const bool tiled = try_tile && face_tile(cseed);
+#ifdef VANERF_MESH_PHASES
+        if (lane == 0) { ph[tiled ? 8 : 9] += 1; const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (tiled) ph[10] += t_ - tprev; }
+#endif
+        if (!tiled) { best = INFINITY; bf = 0x7fffffff; eval_cluster(cseed); }
         // (2) the other clusters: 64 at a time against T with the wave's largest bound, the survivors by every lane against its own
         const float capf = wave_max(fminf(best, vb)) * (1.0f + 1e-4f) + 1e-12f;
-        for (int c0 = 0; c0 < A.nc; c0 += 64) {
+        for (int c0 = 0; c0 < (tiled ? 0 : A.nc); c0 += 64) {
             const int cl_ = c0 + lane;
             unsigned long long cm_ = __ballot(cl_ < A.nc && cl_ != cseed && tile_dist2(s_box + 6 * min(cl_, A.nc - 1)) <= capf);
             while (cm_) {
@@ -500,7 +729,7 @@ __global__ __launch_bounds__(MA_BLOCK) void mesh_query_accel_kernel(const Vanerf
     }
 #ifdef VANERF_MESH_PHASES
     if ((threadIdx.x & 63) == 0)
-        for (int k = 0; k < 8; ++k) atomicAdd(&g_ma_phase[k], ph[k]);
+        for (int k = 0; k < 16; ++k) atomicAdd(&g_ma_phase[k], ph[k]);
 #endif
 }
 
@@ -563,7 +792,7 @@ extern "C" int vanerf_mesh_query_accel(const VanerfMeshAccel* accel, const float
         if (!A.vsort || !A.vbox || A.nvc <= 0 || A.nvc > MA_MAX_VCLUSTERS || A.nvc * CL < nv)
             throw_error("vanerf_mesh_query_accel: bad vertex cluster table (nvc=%d nv=%d)", A.nvc, nv);
         const size_t lds = sizeof(float) * ((size_t)A.nvc * CL * 4 + (size_t)A.nvc * 6 + (size_t)A.nc * 6);
-        if (lds > 150 * 1024) throw_error("vanerf_mesh_query_accel: mesh too large for the LDS-resident tables (%zu bytes)", lds);
+        if (lds > 140 * 1024) throw_error("vanerf_mesh_query_accel: mesh too large for the LDS-resident tables (%zu bytes)", lds);
         if (lds > 64 * 1024) // above the default dynamic-LDS limit (gfx950 has 160 KB per CU)
             HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(mesh_query_accel_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         if (n == 0) return;
@@ -581,8 +810,8 @@ extern "C" int vanerf_mesh_query_accel(const VanerfMeshAccel* accel, const float
 extern "C" int vanerf_debug_mesh_phases(unsigned long long* out8, int reset)
 {
     return guarded([&] {
-        HIP_CHECK(hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_ma_phase), sizeof(unsigned long long) * 8));
-        if (reset) { unsigned long long z[8] = {}; HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_ma_phase), z, sizeof z)); }
+        HIP_CHECK(hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_ma_phase), sizeof(unsigned long long) * 16));
+        if (reset) { unsigned long long z[16] = {}; HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_ma_phase), z, sizeof z)); }
     });
 }
 #endif
