@@ -89,6 +89,54 @@ def test_render_novel_views_two_ranks_gloo():
     assert res[0][2] == list(range(7)) and res[1][2] == list(range(7))  # the gather restores orbit order on every rank
 
 
+def _stub_rows(net, tr_batch, cam_tar, rank, world):
+    """What a rank would have marched: its rows of a frame whose pixel (y, x) is ((tag + y) % 256, x, rank of the row's owner) / 255."""
+    from vanerf_amd.parallel import rank_rows
+    h, w, tag = cam_tar["height"], cam_tar["width"], float(cam_tar["K"][0, 3, 3])
+    rows = rank_rows(h, world, rank)
+    img = torch.zeros(len(rows), w, 3)
+    img[..., 0] = ((tag + rows[:, None].float()) % 256) / 255.0
+    img[..., 1] = torch.arange(w)[None].float() / 255.0
+    img[..., 2] = rank / 255.0
+    return img.reshape(-1, 3)
+
+
+def _worker_rays(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from vanerf_amd.novel_views import render_novel_views
+    from vanerf_amd.parallel import rank_rows
+    cams = _tagged(_stub_cameras(3, h=32, w=12))
+    rgb, _ = render_novel_views(None, cams, _tr_batch(), only_renderings=True, rank=rank, world=world, shard="rays", render_rows_fn=_stub_rows)
+    ok = rgb.shape == (3, 32, 12, 3)
+    owner = np.zeros(32, dtype=np.int64)
+    for r in range(world):
+        owner[rank_rows(32, world, r).numpy()] = r
+    for f in range(3):
+        ok = ok and np.array_equal(rgb[f, :, 0, 0], (f + np.arange(32)) % 256) and np.array_equal(rgb[f, 5, :, 1], np.arange(12))
+        ok = ok and np.array_equal(rgb[f, :, 3, 2], owner)  # rows sit where parallel.shard_rows dealt them: 8-row blocks, round robin
+    q.put((rank, bool(ok), owner[:24].tolist()))
+    dist.destroy_process_group()
+
+
+def test_render_novel_views_ray_sharded_two_ranks_gloo():
+    """BASELINE config 4 as written: rays of every frame sharded over the ranks, one image all_gather per frame (src/model.py:513-545 is serial)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31000 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker_rays, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][1] and res[1][1]
+    assert res[0][2] == [0] * 8 + [1] * 8 + [0] * 8  # the tile layout of bench.py --gpus N
+
+
 def test_render_video_writes_pngs_and_gif(tmp_path):
     from PIL import Image
     from vanerf_amd.novel_views import render_video
@@ -248,3 +296,43 @@ def test_per_frame_caches_follow_their_inputs():
     ref = fresh()
     ref.load_state_dict({k: v for k, v in net.state_dict().items() if k.startswith(("geo_encoder.", "tex_encoder."))}, strict=False)
     assert same(d, render(ref, trb, frame)) and differs(d, c)
+
+
+@pytest.mark.gpu
+def test_orbit_frames_against_the_oracle():
+    """BASELINE config 4, values: frames of a get_360cameras orbit rendered through render_novel_views on the HIP path (encoders, per-frame
+    tables, ray kernels, per-sample networks, composite) against the CPU oracle marching the same cameras with the same feature maps:
+    16x16 views, 16 + 16 samples per ray.  uint8 images: equal up to the last step on all but a few pixels (discrete flips, DESIGN.md 5 ii)."""
+    from oracle import vanerf_oracle as orc
+    from vanerf_amd.config import default_config
+    from vanerf_amd.model import VANeRF, get_360cameras
+    from vanerf_amd.novel_views import camera_to_cam_tar, render_novel_views
+    torch.manual_seed(0)
+    cfg = default_config()
+    cfg["models"]["VANeRF"]["dr_kwargs"].update(sample_per_ray_c=16, sample_per_ray_f=16)
+    net = VANeRF(cfg).cuda().eval()
+    net.load_state_dict(synth.make_full_weights(0), strict=False)
+    frame_cpu = synth.make_frame(seed=3, tar_h=16, tar_w=16)
+    frame = synth.to_device(frame_cpu, "cuda")
+    trb = synth.to_tr_batch(frame)
+    centre = frame_cpu["targets"]["vert_world"][0].mean(0)
+    headpose = torch.eye(4)
+    headpose[:3, 3] = centre
+    cams = get_360cameras(headpose[:3, :4].cuda(), 64.0, 1.0, 1.0, 16, 16, 0.71, 1.42, n_frames=8)
+    pick = [0, 1, 3]
+    rgb, _ = render_novel_views(net, [cams[k] for k in pick], trb, only_renderings=True)
+    assert rgb.shape == (3, 16, 16, 3) and rgb.std() > 5
+    with torch.no_grad():
+        feat_geo, feat_tex = net.encoded(trb["im"])
+    sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    fr = dict(frame_cpu, feat_geo=[f.cpu() for f in feat_geo], feat_tex=feat_tex.cpu())
+    for n, k in enumerate(pick):
+        cam_tar = {key: (v.cpu() if torch.is_tensor(v) else v) for key, v in camera_to_cam_tar(cams[k]).items()}
+        ref = orc.batch_render(sd, dict(fr, cam_tar=cam_tar), 1, torch.tensor([[[0, 0]]]), 16, 16)
+        want = (ref["tex_fg_fine"][0].clamp(0.0, 1.0).permute(1, 2, 0) * 255.0).to(torch.uint8).numpy()
+        diff = np.abs(rgb[n].astype(np.int16) - want.astype(np.int16)).max(-1)
+        assert (diff > 1).sum() <= 3, (k, int((diff > 1).sum()), int(diff.max()))
+    assert np.abs(rgb[0].astype(np.int16) - rgb[2].astype(np.int16)).max() > 10  # the orbit moves
+    # the ray-sharded schedule at world = 1 is the same image
+    rgb_r, _ = render_novel_views(net, [cams[0]], trb, only_renderings=True, shard="rays")
+    assert np.array_equal(rgb_r[0], rgb[0])

@@ -29,29 +29,29 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def _run_ranks(target, world=2, attempts=3):
-    """Spawns `world` gloo ranks; a rendezvous on a just-probed free port can lose a race with another process: retried."""
+def _run_ranks(target, world=2):
+    """Spawns `world` gloo ranks on a just-probed free port, ONCE: a hang, a crash or a wrong result of any rank fails the test (a retry
+    loop here used to hide the first two failures)."""
     import queue as _queue
-    for attempt in range(attempts):
-        with socket.socket() as s:
-            s.bind(("127.0.0.1", 0))
-            port = s.getsockname()[1]
-        ctx = mp.get_context("spawn")
-        q = ctx.Queue()
-        procs = [ctx.Process(target=target, args=(r, world, port, q)) for r in range(world)]
-        for p in procs:
-            p.start()
-        try:
-            res = [q.get(timeout=120) for _ in procs]
-        except _queue.Empty:
-            res = None
-        for p in procs:
-            p.join(60)
-            if p.is_alive():
-                p.kill()
-        if res is not None and all(p.exitcode == 0 for p in procs):
-            return sorted(res, key=lambda t: t[0])
-    raise AssertionError("the gloo ranks did not finish")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=target, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    try:
+        res = [q.get(timeout=180) for _ in procs]
+    except _queue.Empty:
+        res = None
+    for p in procs:
+        p.join(60)
+        if p.is_alive():
+            p.kill()
+    assert res is not None, "a gloo rank did not report within 180 s"
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    return sorted(res, key=lambda t: t[0])
 
 
 def test_two_rank_gather():

@@ -149,10 +149,17 @@ def _project(pts, KRT):
 
 def tex_global_vertex_feature(sd, feat_tex, img, pre="tex_vis_fusion."):
     """TexVisFusion's per-frame global feature (src/networks.py:273-278): (B,1558,18)."""
+    def conv3x3(x, w):
+        # Conv2d(k=3, padding=1, bias=False) as im2col + one GEMM (rocBLAS): for these 3 / 8 / 21-channel, 64^2 / 256^2 maps MIOpen's
+        # solver search lands on naive_conv_ab_nonpacked_fwd_nchw (2.3 ms per call in the first frame's search, profiles/r01_i_*)
+        B, C, H, W = x.shape
+        cols = F.unfold(x, 3, padding=1)  # (B, C*9, H*W), channel-major then kernel position: the layout of w.reshape(O, C*9)
+        return (w.reshape(w.shape[0], -1) @ cols).view(B, w.shape[0], H, W)
+
     def stack(x, name, hw):
-        x = F.conv2d(x, sd[pre + name + ".0.weight"], padding=1)
+        x = conv3x3(x, sd[pre + name + ".0.weight"])
         x = torch.relu(F.layer_norm(x, [hw, hw], sd[pre + name + ".1.weight"], sd[pre + name + ".1.bias"], 1e-6))
-        x = F.conv2d(x, sd[pre + name + ".3.weight"], padding=1)
+        x = conv3x3(x, sd[pre + name + ".3.weight"])
         x = torch.relu(F.layer_norm(x, [hw, hw], sd[pre + name + ".4.weight"], sd[pre + name + ".4.bias"], 1e-6))
         return F.adaptive_avg_pool2d(x, 3)
 
@@ -590,10 +597,10 @@ def render_pass(weights, frame, cam_tar, bounds, x0, y0, step, nx, ny, sample_pe
         if noise_std > 0.0:  # th.randn_like(rad) * rand_noise_std (src/model.py:1155-1156), drawn on the device
             draws = torch.randn(pts.shape[0], device=pts.device, generator=generator) if draws is None else draws.reshape(-1).to(pts.device, torch.float32)
             noise = (draws * noise_std).contiguous()
-        if kernel_events is not None:  # HIP events around the dominant kernel, on the stream it is launched on
+        order = query_order(frame, pts) if pts.shape[0] >= PARTITION_MIN_SAMPLES else None
+        if kernel_events is not None:  # HIP events around the dominant kernel alone (the partition kernels are outside), on the stream it is launched on
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        order = query_order(frame, pts) if pts.shape[0] >= PARTITION_MIN_SAMPLES else None
         rgba = query_samples(weights, frame, pts, q_sdf, q_vis, knn, noise, order=order)
         if kernel_events is not None:
             e1.record()
