@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define VANERF_ABI_VERSION 4
+#define VANERF_ABI_VERSION 5
 
 #define VANERF_OK 0
 #define VANERF_EINVAL (-22)
@@ -217,6 +217,49 @@ int vanerf_importance_merge(const float* contrib, const float* z, const float* u
  *     z_mid[R][n_bins+1] -> z_new[R][Sf]; idx[R][Sf] (searchsorted index after clamping, may be NULL).                     */
 int vanerf_importance_sample(const float* contrib_inner, const float* z_mid, const float* u, const float* t_lin, int R, int n_bins,
                              int Sf, float* z_new, int32_t* idx, void* stream);
+
+/* One whole pass -- VANeRF.batch_render_pifu_nerf without its GT-gather tail (src/model.py:1102-1360): rays, bbox clip, coarse depths,
+ * mesh queries, validity partition, per-sample networks, composite, importance sampling + merge, fine march, fine composite -- as ONE call that
+ * enqueues the kernels above on `stream` in the order vanerf_amd/renderer.py:render_pass does (same kernels, same arguments: same bits).
+ * No allocation, no host synchronisation: all temporaries live in `scratch` (device memory of at least vanerf_render_pass_scratch(...) bytes,
+ * caller-owned; two passes may run concurrently on different streams with different scratch blocks and the same weights handle).            */
+typedef struct {
+    int x0, y0, step_x, step_y, y_block, nx, ny; /* pixel grid as in vanerf_ray_setup (ignored when pixels_xy is given; then n_rays = nx * ny) */
+    const int32_t* pixels_xy;  /* optional explicit pixel list [nx*ny][2] (device), as in vanerf_ray_setup_pixels */
+    int width;                 /* target image width (pixel index = x + y * width) */
+    float invK_T[9], RT[12];   /* target camera: inverse(K[:3,:3]) transposed; [R|t] rows 0..2 */
+    float znear, zfar;
+    float bounds[6];           /* {min xyz, max xyz} of the mesh bounding box (config['bounds']) */
+    int Sc, Sf;                /* sample_per_ray_c, sample_per_ray_f */
+    int fine;                  /* config['fine'] */
+    int reuse_coarse;          /* 1: the fine composite re-uses the coarse evaluations (only the Sf new samples are evaluated; identical bits);
+                                  forced to 0 when noise_c is given (the reference draws fresh noise for re-evaluated samples) */
+    const float* t_lin_c;      /* th.linspace(0, 1, Sc) (device) */
+    const float* t_lin_f;      /* th.linspace(0, 1, Sf) (device); used when u == NULL (uniform=True) */
+    const float* jitter;       /* [R][Sc] stratification draws or NULL (uniform=True) */
+    const float* u;            /* [R][Sf] importance draws or NULL */
+    const float* noise_c;      /* [R*Sc] rand_noise_std * randn draws for the coarse march, or NULL */
+    const float* noise_f;      /* [R*(Sc+Sf)] the same for the fine march (required with noise_c when fine) */
+} VanerfPassDesc;
+
+typedef struct {               /* all device pointers; R = nx * ny */
+    int64_t* index;            /* [R]    pixel index */
+    uint8_t* hit;              /* [R]    ray crosses the bounding box */
+    float* z;                  /* [R][Sc] coarse depths */
+    float* color;              /* [R][3] coarse colour   (tex_fg)   */
+    float* depth;              /* [R]                    (depth)    */
+    float* alpha;              /* [R]                    (alpha)    */
+    float* color_fine;         /* [R][3] (tex_fg_fine); the four fine outputs may be NULL when fine == 0 */
+    float* depth_fine;         /* [R] */
+    float* alpha_fine;         /* [R] */
+    float* sdf;                /* [R] */
+    float* z_fine;             /* [R][Sc+Sf] merged depths, or NULL */
+} VanerfPassOut;
+
+int64_t vanerf_render_pass_scratch(int n_rays, int Sc, int Sf, int fine, int reuse_coarse);
+int vanerf_render_pass(const VanerfWeights* w, const VanerfFrame* frame, const VanerfMeshAccel* accel, const float* verts, int nv,
+                       const int32_t* faces, int nf, const VanerfPassDesc* desc, const VanerfPassOut* out, void* scratch, int64_t scratch_bytes,
+                       void* stream);
 
 /* a3  ray_bbox_intersection (src/model.py:1496-1570) alone: bounds[6], orig[3] (host values), dirs[R][3] (device)
  *     -> near[R], far[R] (1.0 when the ray does not cross the box exactly twice), hit[R] (u8).                               */

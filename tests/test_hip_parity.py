@@ -723,3 +723,36 @@ def test_host_copies_follow_the_device_tensor(R):
     R.prefetch_host_copies(many + [t])
     for m in many:
         assert torch.equal(R.host_copy(m), m.cpu())
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_one_call_pass_equals_the_python_sequence(R, sd_full, precision):
+    """vanerf_render_pass (include/vanerf_hip.h: the whole pass as ONE C call with caller-provided scratch) against renderer.render_pass,
+    which sequences the same entry points from Python: bit-identical outputs -- evaluation grid (with and without the validity partition,
+    i.e. above and below 2^18 samples per launch), coarse re-use on and off, a multi-GPU row shard, and a training pass (explicit pixel
+    list, stratified depths, random importance draws, noise)."""
+    frame = _frame(11, 512, 15.0, tar_w=334)
+    fdat = _frame_data(R, sd_full, frame)
+    w = R.PackedWeights(sd_full, mode=precision)
+    cam, b = frame["cam_tar"], frame["bounds"]
+    keys = ("index", "hit", "z", "color", "depth", "alpha", "color_fine", "depth_fine", "alpha_fine", "sdf", "z_fine")
+
+    def same(a, c):
+        for k in keys:
+            assert torch.equal(a[k], c[k]), k
+
+    same(R.render_pass(w, fdat, cam, b, 0, 0, 2, 167, 256, 16, 16), R.render_pass_c(w, fdat, cam, b, 0, 0, 2, 167, 256, 16, 16))        # 684 k samples: partitioned
+    same(R.render_pass(w, fdat, cam, b, 5, 3, 16, 20, 32, 64, 64), R.render_pass_c(w, fdat, cam, b, 5, 3, 16, 20, 32, 64, 64))            # 41 k samples: not partitioned
+    same(R.render_pass(w, fdat, cam, b, 1, 2, 8, 40, 60, 24, 40, reuse_coarse=False), R.render_pass_c(w, fdat, cam, b, 1, 2, 8, 40, 60, 24, 40, reuse_coarse=False))
+    kw = dict(y_step=32, y_block=8)
+    same(R.render_pass(w, fdat, cam, b, 0, 8, 1, 334, 128, 8, 8, **kw), R.render_pass_c(w, fdat, cam, b, 0, 8, 1, 334, 128, 8, 8, **kw))  # rank 1 of 4
+    g = torch.Generator(device="cuda").manual_seed(5)
+    n, S = 32 * 32, 16
+    yy, xx = torch.meshgrid(torch.arange(32, device="cuda") + 200, torch.arange(32, device="cuda") + 150, indexing="ij")
+    kw = dict(pixels=torch.stack([xx, yy], -1).view(-1, 2).to(torch.int32).contiguous(), jitter=torch.rand(n, S, device="cuda", generator=g),
+              u=torch.rand(n, S, device="cuda", generator=g), noise_std=0.01,
+              noise_draws=(torch.randn(n * S, device="cuda", generator=g), torch.randn(n * 2 * S, device="cuda", generator=g)))
+    same(R.render_pass(w, fdat, cam, b, 0, 0, 1, n, 1, S, S, **kw), R.render_pass_c(w, fdat, cam, b, 0, 0, 1, n, 1, S, S, **kw))
+    c = R.render_pass_c(w, fdat, cam, b, 5, 3, 16, 20, 32, 64, 64, fine=False)
+    assert "color_fine" not in c and torch.equal(c["color"], R.render_pass(w, fdat, cam, b, 5, 3, 16, 20, 32, 64, 64, fine=False)["color"])
+    torch.cuda.synchronize()

@@ -12,7 +12,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int64, c_uint
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VANERF_HIP_LIB") or os.path.join(_HERE, "lib", "libvanerf_hip.so")  # the override is for A/B runs of kernel builds (tools/)
-ABI_VERSION = 4
+ABI_VERSION = 5
 NUM_LAYERS = 20
 
 if not os.path.exists(LIB_PATH):
@@ -53,6 +53,20 @@ class VanerfMeshAccel(Structure):
     ]
 
 
+class VanerfPassDesc(Structure):
+    _fields_ = [
+        ("x0", c_int), ("y0", c_int), ("step_x", c_int), ("step_y", c_int), ("y_block", c_int), ("nx", c_int), ("ny", c_int),
+        ("pixels_xy", _FP), ("width", c_int), ("invK_T", c_float * 9), ("RT", c_float * 12), ("znear", c_float), ("zfar", c_float),
+        ("bounds", c_float * 6), ("Sc", c_int), ("Sf", c_int), ("fine", c_int), ("reuse_coarse", c_int),
+        ("t_lin_c", _FP), ("t_lin_f", _FP), ("jitter", _FP), ("u", _FP), ("noise_c", _FP), ("noise_f", _FP),
+    ]
+
+
+class VanerfPassOut(Structure):
+    _fields_ = [("index", _FP), ("hit", _FP), ("z", _FP), ("color", _FP), ("depth", _FP), ("alpha", _FP), ("color_fine", _FP), ("depth_fine", _FP),
+                ("alpha_fine", _FP), ("sdf", _FP), ("z_fine", _FP)]
+
+
 _SIGS = {
     "vanerf_abi_version": (c_int, []),
     "vanerf_last_error": (c_char_p, []),
@@ -78,6 +92,9 @@ _SIGS = {
     "vanerf_composite_merged": (c_int, [_FP, _FP, c_int, _FP, _FP, c_int, _FP, _FP, c_int, c_float, _FP, _FP, _FP, _FP, _FP, c_void_p]),
     "vanerf_importance_merge": (c_int, [_FP, _FP, _FP, _FP, c_int, c_int, c_int, _FP, _FP, _FP, _FP, c_void_p]),
     "vanerf_importance_sample": (c_int, [_FP, _FP, _FP, _FP, c_int, c_int, c_int, _FP, _FP, c_void_p]),
+    "vanerf_render_pass_scratch": (c_int64, [c_int, c_int, c_int, c_int, c_int]),
+    "vanerf_render_pass": (c_int, [c_void_p, POINTER(VanerfFrame), POINTER(VanerfMeshAccel), _FP, c_int, _FP, c_int, POINTER(VanerfPassDesc),
+                                   POINTER(VanerfPassOut), _FP, c_int64, c_void_p]),
     "vanerf_ray_bbox": (c_int, [POINTER(c_float), POINTER(c_float), _FP, c_int, _FP, _FP, _FP, c_void_p]),
 }
 EXPORTS = tuple(_SIGS)

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <stdexcept>
@@ -76,6 +77,6 @@ struct VanerfWeights {
     // work-queue heads of query_kernel (one per launch, used round robin; zeroed on the launch stream before each use)
     static constexpr int N_QUEUES = 64;
     unsigned* queues = nullptr;
-    unsigned next_queue = 0;
+    mutable std::atomic<unsigned> next_queue{0}; // two host threads may launch with the same handle: each launch takes its own slot
     unsigned long long* stats = nullptr; // [0]: running count of 32-sample groups that took query_kernel's all-invalid short path
 };

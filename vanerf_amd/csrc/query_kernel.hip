@@ -892,8 +892,7 @@ extern "C" int vanerf_query_samples(const VanerfWeights* w, const VanerfFrame* f
         if (const char* e = getenv("VANERF_BLOCKS_PER_CU")) per_cu = atoi(e) > 0 ? atoi(e) : 2; // experiment knob
         long long cap = (long long)cus * per_cu;
         if (blocks > cap) blocks = cap;
-        VanerfWeights* wm = const_cast<VanerfWeights*>(w);
-        P.queue = wm->queues + (wm->next_queue++ % VanerfWeights::N_QUEUES);
+        P.queue = w->queues + (w->next_queue.fetch_add(1u, std::memory_order_relaxed) % VanerfWeights::N_QUEUES);
         HIP_CHECK(hipMemsetAsync(P.queue, 0, sizeof(unsigned), (hipStream_t)stream));
         if (w->mode == 1) hipLaunchKernelGGL(query_kernel<1>, dim3((unsigned)blocks), dim3(BLOCK), 0, (hipStream_t)stream, P);
         else hipLaunchKernelGGL(query_kernel<0>, dim3((unsigned)blocks), dim3(BLOCK), 0, (hipStream_t)stream, P);
@@ -1010,8 +1009,7 @@ extern "C" int vanerf_debug_query_stamps(const VanerfWeights* w, const VanerfFra
         if (const char* e = getenv("VANERF_BLOCKS_PER_CU")) capd = 256LL * (atoi(e) > 0 ? atoi(e) : 2);
         if (blocks > capd) blocks = capd;
         *n_waves = (int)blocks * WAVES_PER_BLOCK;
-        VanerfWeights* wm = const_cast<VanerfWeights*>(w);
-        P.queue = wm->queues + (wm->next_queue++ % VanerfWeights::N_QUEUES);
+        P.queue = w->queues + (w->next_queue.fetch_add(1u, std::memory_order_relaxed) % VanerfWeights::N_QUEUES);
         HIP_CHECK(hipMemsetAsync(P.queue, 0, sizeof(unsigned), (hipStream_t)stream));
         if (stamps && w->mode == 1) hipLaunchKernelGGL(query_kernel<1>, dim3((unsigned)blocks), dim3(BLOCK), 0, (hipStream_t)stream, P);
         else if (stamps) hipLaunchKernelGGL(query_kernel<0>, dim3((unsigned)blocks), dim3(BLOCK), 0, (hipStream_t)stream, P);

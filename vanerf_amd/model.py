@@ -387,8 +387,10 @@ class VANeRF(nn.Module):
             u = None if uniform else torch.rand(Rn, Sf, device=dev)                # th.rand(...), src/model.py:1443
         noise_draws = (draws["noise_c"], draws["noise_f"]) if draws is not None and noise_std > 0.0 else None
         want_graph = bool(config.get("_autograd", False))  # forward() under autograd: keep what vanerf_amd.torch_graph needs
-        o = R.render_pass(net.packed_weights(), fd, cam_t, config["bounds"], x0, y0, step, nx, ny, Sc, Sf, fine=fine, jitter=jitter, u=u,
-                          noise_std=float(noise_std), pixels=pixels, debug=want_graph, noise_draws=noise_draws)
+        # one C call (vanerf_render_pass) unless the autograd graph needs the intermediates of the Python sequence
+        run = R.render_pass if want_graph else R.render_pass_c
+        o = run(net.packed_weights(), fd, cam_t, config["bounds"], x0, y0, step, nx, ny, Sc, Sf, fine=fine, jitter=jitter, u=u,
+                noise_std=float(noise_std), pixels=pixels, noise_draws=noise_draws, **({"debug": True} if want_graph else {}))
         if want_graph:
             net._last_pass = (o, fd, cam_in)
         out = {"tex_fg": o["color"].view(1, out_h, out_w, 3).permute(0, 3, 1, 2), "depth": o["depth"].view(1, out_h, out_w),

@@ -12,7 +12,7 @@ import torch
 import torch.nn.functional as F
 
 from . import _ffi
-from ._ffi import VanerfFrame, VanerfMeshAccel, VanerfWeightTable, check, lib
+from ._ffi import VanerfFrame, VanerfMeshAccel, VanerfPassDesc, VanerfPassOut, VanerfWeightTable, check, lib
 
 NV, NV_HAND, NKPT = 1558, 779, 42
 
@@ -631,4 +631,49 @@ def render_pass(weights, frame, cam_tar, bounds, x0, y0, step, nx, ny, sample_pe
         if debug:
             out["fine"] = f
             out["fine_src"] = src if reuse_coarse else None
+    return out
+
+
+def render_pass_c(weights, frame, cam_tar, bounds, x0, y0, step, nx, ny, sample_per_ray_c=64, sample_per_ray_f=64, fine=True, jitter=None, u=None,
+                  noise_std=0.0, generator=None, y_step=None, reuse_coarse=True, pixels=None, y_block=1, noise_draws=None):
+    """The same pass through the single C entry point vanerf_render_pass (include/vanerf_hip.h): one ctypes call enqueues every kernel of
+    render_pass() above, in the same order with the same arguments -- the outputs are bit-identical (tests/test_hip_parity.py) -- with all
+    temporaries in one scratch block.  This is what a non-Python host binds; the model's eval / no-grad passes go through it too."""
+    Sc, Sf, R = int(sample_per_ray_c), int(sample_per_ray_f), nx * ny
+    dev = frame.verts3.device
+    K, RT = host_copy(cam_tar["K"]), host_copy(cam_tar["RT"])
+    d = VanerfPassDesc()
+    d.x0, d.y0, d.step_x, d.step_y, d.y_block, d.nx, d.ny = int(x0), int(y0), int(step), int(y_step or step), int(y_block), int(nx), int(ny)
+    d.pixels_xy = _ptr(pixels, torch.int32)
+    d.width = int(cam_tar["width"])
+    d.invK_T = _farr(torch.inverse(K[:, :3, :3]).transpose(1, 2)[0].reshape(-1).tolist(), 9)
+    d.RT = _farr(RT[0, :3, :4].reshape(-1).tolist(), 12)
+    d.znear, d.zfar = float(cam_tar["znear"]), float(cam_tar["zfar"])
+    d.bounds = _farr(host_copy(bounds).reshape(-1).tolist(), 6)
+    d.Sc, d.Sf, d.fine = Sc, Sf, int(bool(fine))
+    noise = None
+    if noise_std > 0.0:  # th.randn_like(rad) * rand_noise_std (src/model.py:1155-1156), drawn on the device (or handed in)
+        draws = noise_draws if noise_draws is not None else (torch.randn(R * Sc, device=dev, generator=generator),
+                                                             torch.randn(R * (Sc + Sf), device=dev, generator=generator) if fine else None)
+        noise = tuple(None if t is None else (t.reshape(-1).to(dev, torch.float32) * noise_std).contiguous() for t in draws)
+    d.reuse_coarse = int(bool(reuse_coarse) and noise is None)
+    t_c, t_f = _t_lin(Sc, dev), _t_lin(Sf, dev) if fine else None
+    d.t_lin_c, d.t_lin_f = _ptr(t_c), _ptr(t_f)
+    d.jitter, d.u = _ptr(jitter, torch.float32), _ptr(u, torch.float32)
+    d.noise_c, d.noise_f = (_ptr(noise[0]), _ptr(noise[1])) if noise is not None else (None, None)
+    f32 = torch.float32
+    out = {"index": torch.empty(R, dtype=torch.int64, device=dev), "hit": torch.empty(R, dtype=torch.uint8, device=dev),
+           "z": torch.empty(R, Sc, dtype=f32, device=dev), "color": torch.empty(R, 3, dtype=f32, device=dev),
+           "depth": torch.empty(R, dtype=f32, device=dev), "alpha": torch.empty(R, dtype=f32, device=dev)}
+    if fine:
+        out.update({"color_fine": torch.empty(R, 3, dtype=f32, device=dev), "depth_fine": torch.empty(R, dtype=f32, device=dev),
+                    "alpha_fine": torch.empty(R, dtype=f32, device=dev), "sdf": torch.empty(R, dtype=f32, device=dev),
+                    "z_fine": torch.empty(R, Sc + Sf, dtype=f32, device=dev)})
+    o = VanerfPassOut()
+    for k in ("index", "hit", "z", "color", "depth", "alpha", "color_fine", "depth_fine", "alpha_fine", "sdf", "z_fine"):
+        setattr(o, k, _ptr(out.get(k)))
+    nbytes = int(lib.vanerf_render_pass_scratch(R, Sc, Sf, d.fine, d.reuse_coarse))
+    scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    check(lib.vanerf_render_pass(weights.handle, byref(frame.c), byref(frame.accel.c), _ptr(frame.verts3, f32), frame.verts3.shape[0],
+                                 _ptr(frame.faces, torch.int32), frame.faces.shape[0], byref(d), byref(o), _ptr(scratch), nbytes, _stream()))
     return out
