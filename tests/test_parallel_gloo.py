@@ -87,7 +87,8 @@ def _grad_worker(rank, world, port, q):
     x = torch.full((4, 7), float(rank + 1))
     net[:2](x).sum().backward()  # the last layer gets no gradient on any rank, like the IBR head at one source view
     calls = all_reduce_gradients(net.parameters(), world, bucket_bytes=64)  # tiny buckets: several collectives
-    q.put((rank, calls, [p.grad.clone() for p in net.parameters()]))
+    # plain lists, not tensors: a tensor in a queue travels as a file descriptor served by THIS process, which may be gone before the parent asks
+    q.put((rank, calls, [p.grad.reshape(-1).tolist() for p in net.parameters()]))
     dist.destroy_process_group()
 
 
@@ -106,7 +107,7 @@ def test_two_rank_gradient_average():
     assert res[0][1] == res[1][1] and res[0][1] > 1
     for rank_res in res:
         for got, w in zip(rank_res[2], want):
-            assert torch.allclose(got, w, atol=1e-6)
+            assert torch.allclose(torch.tensor(got), w.reshape(-1), atol=1e-6)
 
 
 H4 = 64
