@@ -171,6 +171,9 @@ __device__ __forceinline__ void run_layer(f32x16 (&acc)[NB], Ring<NB>& ring, WRs
 // ring depths (steps in flight) for layers with 4/3, 1 and 2 output blocks.  With the pinned software pipeline of run_layer_b, measured in
 // one session: (2,4,2) 8.16-8.23 ms, (2,3,2) 8.22, (2,2,2) 8.24, (1,4,2) 8.25, (3,6,3) 8.32, (1,2,1) 8.33, (4,8,4) +4 %, (5,8,4) +8 %:
 // two k-steps ahead cover the L2 latency, deeper rings only add loads in flight
+#ifndef VANERF_CHUNKS
+#define VANERF_CHUNKS 4
+#endif
 #ifndef VANERF_RINGB_WIDE
 #define VANERF_RINGB_WIDE 2
 #endif
@@ -184,13 +187,33 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
 template <int NB> struct WFragB { u32x4 hi[NB], lo[NB]; };
+
+// Fragments of the LAST layers of the stream stay resident in LDS for the whole launch (split-bf16 kernel: one block per CU, persistent):
+// every group needs them -- the all-invalid groups need nothing else -- and the CU's vector-memory path (L1: 64 B per clock) is what the
+// fragment stream loads most (72 % of its cycles, profiles/r02_a_*): ds_read_b128 has four times that width and a fifth of the latency.
+// Layers VANERF_LDS_FIRST .. NUM_LAYERS-1 are copied once per block: head1, head2, ibr_compress and the four TexVisFusion layers = 156 KB.
+#ifndef VANERF_LDS_FIRST
+#define VANERF_LDS_FIRST 13 /* L_HEAD1 */
+#endif
+constexpr int LDS_FIRST = VANERF_LDS_FIRST;
+constexpr unsigned RES_BASE_DW = layer_offset_b(LDS_FIRST), RES_DW = layer_offset_b(NUM_LAYERS) - layer_offset_b(LDS_FIRST);
+static_assert(RES_DW * 4u + 256u <= 160u * 1024u, "resident fragments + the block's small static LDS must fit the CU's 160 KB");
+extern __shared__ u32x4 s_wres[];
 template <int NB> struct RingDepthB { static constexpr int value = NB == 1 ? VANERF_RINGB_D1 : (NB == 2 ? VANERF_RINGB_D2 : VANERF_RINGB_WIDE); };
 template <int NB> struct RingB { WFragB<NB> f[RingDepthB<NB>::value]; };
 
 // step_dw: dword offset of (step, block 0, hi) in the stream; vb = lane * 16 bytes
-template <int NB> __device__ __forceinline__ WFragB<NB> wload_b(WRsrc rs, unsigned step_dw, unsigned vb)
+template <int NB, bool RES = false> __device__ __forceinline__ WFragB<NB> wload_b(WRsrc rs, unsigned step_dw, unsigned vb)
 {
     WFragB<NB> r;
+    if constexpr (RES) { // resident layer: the same fragments from LDS
+#pragma unroll
+        for (int ob = 0; ob < NB; ++ob) {
+            r.hi[ob] = s_wres[(step_dw - RES_BASE_DW + (ob * 2 + 0) * 256) / 4 + (vb >> 4)];
+            r.lo[ob] = s_wres[(step_dw - RES_BASE_DW + (ob * 2 + 1) * 256) / 4 + (vb >> 4)];
+        }
+        return r;
+    }
 #pragma unroll
     for (int ob = 0; ob < NB; ++ob) {
         r.hi[ob] = __builtin_amdgcn_raw_buffer_load_b128(rs, vb, (step_dw + (ob * 2 + 0) * 256) * 4u, 0);
@@ -199,13 +222,13 @@ template <int NB> __device__ __forceinline__ WFragB<NB> wload_b(WRsrc rs, unsign
     return r;
 }
 
-template <int NB, int T> __device__ __forceinline__ RingB<NB> ring_start_b(WRsrc rs, unsigned sbase_dw, unsigned vb)
+template <int NB, int T, bool RES = false> __device__ __forceinline__ RingB<NB> ring_start_b(WRsrc rs, unsigned sbase_dw, unsigned vb)
 {
     constexpr int D = RingDepthB<NB>::value, S = (T + 7) / 8;
     RingB<NB> r;
     static_for<D>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
-        if constexpr (i < S) r.f[i] = wload_b<NB>(rs, sbase_dw + i * NB * 512, vb);
+        if constexpr (i < S) r.f[i] = wload_b<NB, RES>(rs, sbase_dw + i * NB * 512, vb);
     });
     __builtin_amdgcn_sched_barrier(0x000F); // keep the ring fill where it is written: ahead of the previous layer's epilogue
     return r;
@@ -229,11 +252,12 @@ struct NoPre { template <class C> __device__ __forceinline__ void operator()(C) 
 // So: step s's MFMAs are cut into four chunks, after each chunk comes one pair-split of step s+1's operands (5 VALU), the re-load of
 // the consumed ring slot is issued before the first chunk, and a sched_barrier(0) after every chunk keeps that order.
 // (sched_group_barrier could request the same interleave, but its solver did not finish on this 10 k-instruction block in 15 min.)
-template <int NB, int T, class Op, class Pre = NoPre>
+template <int NB, int T, bool RES = false, class Op, class Pre = NoPre>
 __device__ __forceinline__ void run_layer_b(f32x16 (&acc)[NB], RingB<NB>& ring, WRsrc rs, unsigned sbase_dw, unsigned vb, Op&& operand,
                                             Pre&& pre = Pre{})
 {
     constexpr int D = RingDepthB<NB>::value, S = (T + 7) / 8;
+    constexpr int NCH = VANERF_CHUNKS; // chunks a step's MFMAs are cut into (4 / NCH operand pairs of the next step are split after each)
     // hi = bf16(x) (round to nearest even), lo = bf16(x - hi) for operand pair i of step s: 6 VALU -- v_cvt_pk, v_lshlrev, v_and, two
     // v_sub_f32, v_cvt_pk (no packed f32 math: a v_pk_add_f32 beside MFMAs costs more than the two scalar ops it replaces, and the file
     // is built with -fno-slp-vectorize for the same reason).  The empty asm keeps the packed hi opaque: without it the compiler
@@ -255,22 +279,22 @@ __device__ __forceinline__ void run_layer_b(f32x16 (&acc)[NB], RingB<NB>& ring, 
     static_for<S>([&](auto sc) {
         constexpr int s = decltype(sc)::value;
         const WFragB<NB> a = ring.f[s % D];
-        if constexpr (s + D < S) ring.f[s % D] = wload_b<NB>(rs, sbase_dw + (s + D) * NB * 512, vb);
+        if constexpr (s + D < S) ring.f[s % D] = wload_b<NB, RES>(rs, sbase_dw + (s + D) * NB * 512, vb);
         const bf16x8 xh = __builtin_bit_cast(bf16x8, bh), xl = __builtin_bit_cast(bf16x8, bl);
         u32x4 nh = {}, nl = {};
         // MFMA m of the step (m = 3*ob + product) belongs to chunk m * 4 / (3*NB); products of one block stay in order hh, hl, lh
-        static_for<4>([&](auto cc) {
+        static_for<NCH>([&](auto cc) {
             constexpr int c = decltype(cc)::value;
             static_for<3 * NB>([&](auto mc) {
                 constexpr int m = decltype(mc)::value, ob = m / 3, pr = m % 3;
-                if constexpr (m * 4 / (3 * NB) == c) {
+                if constexpr (m * NCH / (3 * NB) == c) {
                     const bf16x8 wh = __builtin_bit_cast(bf16x8, a.hi[ob]), wl = __builtin_bit_cast(bf16x8, a.lo[ob]);
                     acc[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pr == 2 ? wl : wh, pr == 1 ? xl : xh, acc[ob], 0, 0, 0);
                 }
             });
             if constexpr (s + 1 < S) {
                 if constexpr (c == 0) pre(std::integral_constant<int, s + 1>{});
-                split_pair(std::integral_constant<int, s + 1>{}, cc, nh, nl);
+                static_for<4 / NCH>([&](auto pc) { split_pair(std::integral_constant<int, s + 1>{}, std::integral_constant<int, c * (4 / NCH) + decltype(pc)::value>{}, nh, nl); });
             }
             __builtin_amdgcn_sched_barrier(0);
         });
@@ -285,14 +309,14 @@ template <int NB> struct RingSel<1, NB> { using type = RingB<NB>; };
 template <int MODE, int NB, int T, int L> __device__ __forceinline__ typename RingSel<MODE, NB>::type ring_start_m(WRsrc rs, int lane)
 {
     if constexpr (MODE == 0) return ring_start<NB, T>(rs, layer_offset(L), (unsigned)lane * NB * 4u);
-    else return ring_start_b<NB, T>(rs, layer_offset_b(L), (unsigned)lane * 16u);
+    else return ring_start_b<NB, T, (L >= LDS_FIRST)>(rs, layer_offset_b(L), (unsigned)lane * 16u);
 }
 
 template <int MODE, int NB, int T, int L, class Op>
 __device__ __forceinline__ void run_layer_m(f32x16 (&acc)[NB], typename RingSel<MODE, NB>::type& ring, WRsrc rs, int lane, Op&& operand)
 {
     if constexpr (MODE == 0) run_layer<NB, T>(acc, ring, rs, layer_offset(L), (unsigned)lane * NB * 4u, static_cast<Op&&>(operand));
-    else run_layer_b<NB, T>(acc, ring, rs, layer_offset_b(L), (unsigned)lane * 16u, static_cast<Op&&>(operand));
+    else run_layer_b<NB, T, (L >= LDS_FIRST)>(acc, ring, rs, layer_offset_b(L), (unsigned)lane * 16u, static_cast<Op&&>(operand));
 }
 
 template <int NB> __device__ __forceinline__ void zero(f32x16 (&acc)[NB])
@@ -531,6 +555,10 @@ __global__ __launch_bounds__(BLOCK, MODE == 1 ? VANERF_WAVES_PER_SIMD_B : VANERF
     const unsigned wv = threadIdx.x >> 6;
     unsigned pending = 0, par = 1;
     if (threadIdx.x == 0) s_base[0] = atomicAdd(P.queue, (unsigned)WAVES_PER_BLOCK);
+    if constexpr (MODE == 1) { // resident fragments: one copy per block (the launch is persistent: 256 blocks x 156 KB from L2, once)
+        const u32x4* __restrict__ src = reinterpret_cast<const u32x4*>(P.w) + RES_BASE_DW / 4;
+        for (unsigned i = threadIdx.x; i < RES_DW / 4; i += BLOCK) s_wres[i] = src[i];
+    }
     __syncthreads();
     unsigned base_cur = s_base[0];
     if (threadIdx.x == 0) pending = atomicAdd(P.queue, (unsigned)WAVES_PER_BLOCK);
@@ -707,7 +735,7 @@ __global__ __launch_bounds__(BLOCK, MODE == 1 ? VANERF_WAVES_PER_SIMD_B : VANERF
                         // 179 the bias.  A bf16 step takes 8 consecutive pairs, so key point i is computed right before the first step
                         // that needs it (at most two key points are live at a time).
                         float feat[PE_KPT_PER_HALF][PE_FEATS];
-                        run_layer_b<4, 180>(a0, ring0b, W, layer_offset_b(L_MLP0), (unsigned)lane * 16u,
+                        run_layer_b<4, 180, false>(a0, ring0b, W, layer_offset_b(L_MLP0), (unsigned)lane * 16u,
                             [&](auto tc) -> float {
                                 constexpr int t = decltype(tc)::value;
                                 if constexpr (t < 147) return feat[t / 7][t % 7];
@@ -894,8 +922,11 @@ extern "C" int vanerf_query_samples(const VanerfWeights* w, const VanerfFrame* f
         if (blocks > cap) blocks = cap;
         P.queue = w->queues + (w->next_queue.fetch_add(1u, std::memory_order_relaxed) % VanerfWeights::N_QUEUES);
         HIP_CHECK(hipMemsetAsync(P.queue, 0, sizeof(unsigned), (hipStream_t)stream));
-        if (w->mode == 1) hipLaunchKernelGGL(query_kernel<1>, dim3((unsigned)blocks), dim3(BLOCK), 0, (hipStream_t)stream, P);
-        else hipLaunchKernelGGL(query_kernel<0>, dim3((unsigned)blocks), dim3(BLOCK), 0, (hipStream_t)stream, P);
+        if (w->mode == 1) {
+            static const hipError_t lds_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(query_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(RES_DW * 4u));
+            HIP_CHECK(lds_ok);
+            hipLaunchKernelGGL(query_kernel<1>, dim3((unsigned)blocks), dim3(BLOCK), RES_DW * 4u, (hipStream_t)stream, P);
+        } else hipLaunchKernelGGL(query_kernel<0>, dim3((unsigned)blocks), dim3(BLOCK), 0, (hipStream_t)stream, P);
         HIP_CHECK(hipGetLastError());
     });
 }
@@ -1011,7 +1042,7 @@ extern "C" int vanerf_debug_query_stamps(const VanerfWeights* w, const VanerfFra
         *n_waves = (int)blocks * WAVES_PER_BLOCK;
         P.queue = w->queues + (w->next_queue.fetch_add(1u, std::memory_order_relaxed) % VanerfWeights::N_QUEUES);
         HIP_CHECK(hipMemsetAsync(P.queue, 0, sizeof(unsigned), (hipStream_t)stream));
-        if (stamps && w->mode == 1) hipLaunchKernelGGL(query_kernel<1>, dim3((unsigned)blocks), dim3(BLOCK), 0, (hipStream_t)stream, P);
+        if (stamps && w->mode == 1) hipLaunchKernelGGL(query_kernel<1>, dim3((unsigned)blocks), dim3(BLOCK), RES_DW * 4u, (hipStream_t)stream, P);
         else if (stamps) hipLaunchKernelGGL(query_kernel<0>, dim3((unsigned)blocks), dim3(BLOCK), 0, (hipStream_t)stream, P);
         HIP_CHECK(hipGetLastError());
     });

@@ -456,38 +456,22 @@ class VANeRF(nn.Module):
 
     def attach_autograd(self, out, img_in, feat_geo, feat_tex, targets, sp_data, fg_mask):
         """Replaces the differentiable entries of `out` (a batch_render_pifu_nerf result computed with _autograd=True) by tensors that
-        carry the HIP values and the gradients of vanerf_amd.torch_graph evaluated at the same samples (same points, same importance
-        samples, same mesh queries, same noise draws)."""
+        carry the HIP values and, in backward, the gradients of vanerf_amd.torch_graph evaluated at the same samples (same points, same
+        importance samples, same mesh queries, same noise draws) -- torch_graph.PassGradient: the graph is built and differentiated chunk of
+        rays by chunk of rays inside backward, so a training step never holds the activations of the whole patch."""
         from . import torch_graph as G
         o, fd, cam_in = self._last_pass
         self._last_pass = (o, fd, cam_in) if getattr(self, "_keep_last_pass", False) else None  # tests inspect the pass
-        P = dict(self.named_parameters())
-        frame = {"cam": cam_in, "img": img_in, "feat_geo": feat_geo, "feat_tex": feat_tex, "fg_mask": fg_mask.reshape(1, 1, *fg_mask.shape[-2:]),
-                 "verts": targets["vert_world"][0], "vert_vis": fd.vert_vis, "kpt3d": sp_data["kpt3d"], "extrin": sp_data["extrin"]}
-        frame["table29"] = G.texture_vertex_table(P, G.project_vertices(frame["verts"], cam_in), feat_tex, img_in)
-        Rn = o["z"].shape[0]
-        shape = out["depth"].shape  # (1, h, w)
-
-        def evaluate(c):
-            return G.networks_at(P, frame, c["pts"], c["q_sdf"].reshape(-1), c["q_vis"], c["knn"].long(), c["noise"], self.kwargs["sp_args"]).view(Rn, -1, 5)
-
-        c = o["coarse"]
-        rgba_c = evaluate(c)
-        col, dep, acc, _ = G.composite(P, rgba_c, o["z"], c["q_sdf"])
-        graph = {"tex_fg": col.view(1, *shape[1:], 3).permute(0, 3, 1, 2), "depth": dep.view(shape), "alpha": acc.view(shape)}
-        if "fine" in o:
-            f = o["fine"]
-            rgba_f, msdf = evaluate(f), f["q_sdf"]
-            if o.get("fine_src") is not None:  # the pass re-used the coarse evaluations: merge [coarse | new] by the origin map
-                src = o["fine_src"].long()
-                take = torch.where(src >= 0, src, rgba_c.shape[1] + (-src - 1))
-                rgba_f = torch.gather(torch.cat([rgba_c, rgba_f], 1), 1, take[..., None].expand(-1, -1, 5))
-                msdf = torch.gather(torch.cat([c["q_sdf"], f["q_sdf"]], 1), 1, take)
-            col, dep, acc, sdf = G.composite(P, rgba_f, o["z_fine"], msdf)
-            graph.update({"tex_fg_fine": col.view(1, *shape[1:], 3).permute(0, 3, 1, 2), "depth_fine": dep.view(shape), "alpha_fine": acc.view(shape),
-                          "sdf": sdf.view(shape)})
-        for k, g in graph.items():
-            out[k] = G.straight_through(out[k], g)
+        named = [(k, p) for k, p in self.named_parameters() if not k.startswith(("geo_encoder.", "tex_encoder.", "mlp_tex."))]
+        names = [k for k, _ in named] + ["@feat_geo0", "@feat_geo1", "@feat_tex"]
+        leaves = [p for _, p in named] + [feat_geo[0], feat_geo[1], feat_tex]
+        frame = {"cam": cam_in, "img": img_in, "fg_mask": fg_mask.reshape(1, 1, *fg_mask.shape[-2:]), "verts": targets["vert_world"][0],
+                 "vert_vis": fd.vert_vis, "kpt3d": sp_data["kpt3d"], "extrin": sp_data["extrin"]}
+        keys = [k for k in ("tex_fg", "depth", "alpha", "tex_fg_fine", "depth_fine", "alpha_fine", "sdf") if k in out]
+        spec = {"values": [out[k] for k in keys], "keys": keys, "names": names, "frame": frame, "pass": o, "sp_args": self.kwargs["sp_args"],
+                "rays_per_chunk": self.kwargs.get("grad_rays_per_chunk", G.GRAD_RAYS_PER_CHUNK)}
+        for k, v in zip(keys, G.PassGradient.apply(spec, *leaves)):
+            out[k] = v
         return out
 
     def forward(self, im, cam, hand_type, targets, data, bbox, n_views=1, sp_data={}, dr_data=None, **kwargs):

@@ -202,3 +202,83 @@ def composite(P, rgba, z, mesh_sdf):
 def straight_through(value, graph):
     """HIP value, this module's gradient."""
     return graph + (value - graph).detach()
+
+
+# Rays per chunk of the backward pass (PassGradient); None = the whole patch at once.  The graph of a chunk lives only while its gradient is
+# taken, so chunking bounds the step's peak memory -- at the price of launch-bound kernels.  Measured on the 64x64 patch at 64 + 64 samples
+# (786 k samples, tools/perf_train_step.py, one MI355X): whole patch 97 ms / 10.2 GiB, 2048 rays 115 ms / 5.4 GiB, 1024 rays 155 ms /
+# 3.0 GiB, 512 rays 186 ms / 1.9 GiB.  With 288 GB of HBM the default is speed; model config key `grad_rays_per_chunk` sets it.
+# (bf16 operands for this graph's GEMMs were measured too: 106 ms, and the parameter gradients moved by 4e-2 relative -- dropped.)
+GRAD_RAYS_PER_CHUNK = None
+
+
+class PassGradient(torch.autograd.Function):
+    """forward: the HIP pass's images, unchanged.  backward: the gradients of this module's graph at the samples of that pass with respect to
+    the leaves (the module's parameters and the encoders' feature maps), taken chunk of rays by chunk of rays: rays are independent, so the
+    gradient of the whole patch is the sum over chunks, and only one chunk's activations exist at a time.  The per-frame vertex table of
+    TexVisFusion (two conv stacks over the source image) is shared by all samples: its graph is built once, the chunks accumulate the
+    gradient with respect to the table, and one backward through the stacks closes the step."""
+
+    @staticmethod
+    def forward(ctx, spec, *leaves):
+        ctx.spec = spec
+        ctx.save_for_backward(*leaves)
+        return tuple(v.clone() for v in spec["values"])
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        spec, names = ctx.spec, ctx.spec["names"]
+        with torch.enable_grad():
+            loc = [t.detach().requires_grad_(True) for t in ctx.saved_tensors]
+            L = dict(zip(names, loc))
+            P = {k: v for k, v in L.items() if not k.startswith("@")}
+            frame = dict(spec["frame"], feat_geo=[L["@feat_geo0"], L["@feat_geo1"]], feat_tex=L["@feat_tex"])
+            total = [None] * len(loc)
+
+            def accumulate(grads):
+                for i, g in enumerate(grads):
+                    if g is not None:
+                        total[i] = g if total[i] is None else total[i] + g
+
+            table_graph = texture_vertex_table(P, project_vertices(frame["verts"], frame["cam"]), frame["feat_tex"], frame["img"])
+            table = table_graph.detach().requires_grad_(True)
+            g_table = torch.zeros_like(table)
+            o, keys = spec["pass"], spec["keys"]
+            R = o["z"].shape[0]
+            c, f = o["coarse"], o.get("fine")
+            step = spec["rays_per_chunk"] or R
+            for r0 in range(0, R, step):
+                r1 = min(R, r0 + step)
+
+                def evaluate(part):
+                    S = part["pts"].shape[0] // R
+                    sl = slice(r0 * S, r1 * S)
+                    noise = None if part["noise"] is None else part["noise"][sl]
+                    return networks_at(P, dict(frame, table29=table), part["pts"][sl], part["q_sdf"].reshape(-1)[sl], part["q_vis"][sl],
+                                       part["knn"][sl].long(), noise, spec["sp_args"]).view(r1 - r0, S, 5)
+
+                rgba_c = evaluate(c)
+                col, dep, acc, _ = composite(P, rgba_c, o["z"][r0:r1], c["q_sdf"][r0:r1])
+                outs = {"tex_fg": col, "depth": dep, "alpha": acc}
+                if f is not None:
+                    rgba_f, msdf = evaluate(f), f["q_sdf"][r0:r1]
+                    if o.get("fine_src") is not None:  # the pass re-used the coarse evaluations: merge [coarse | new] by the origin map
+                        src = o["fine_src"][r0:r1].long()
+                        take = torch.where(src >= 0, src, rgba_c.shape[1] + (-src - 1))
+                        rgba_f = torch.gather(torch.cat([rgba_c, rgba_f], 1), 1, take[..., None].expand(-1, -1, 5))
+                        msdf = torch.gather(torch.cat([c["q_sdf"][r0:r1], f["q_sdf"][r0:r1]], 1), 1, take)
+                    col, dep, acc, sdf = composite(P, rgba_f, o["z_fine"][r0:r1], msdf)
+                    outs.update({"tex_fg_fine": col, "depth_fine": dep, "alpha_fine": acc, "sdf": sdf})
+                pairs = []
+                for k, g in zip(keys, gouts):
+                    if g is None:
+                        continue
+                    # images are (1,3,h,w) / (1,h,w) over the patch's rays in row-major order: the chunk's rays are a slice of the flattened image
+                    gk = g.reshape(3, -1).t()[r0:r1] if k.startswith("tex_fg") else g.reshape(-1)[r0:r1]
+                    pairs.append((outs[k], gk))
+                grads = torch.autograd.grad([a for a, _ in pairs], loc + [table], [b for _, b in pairs], allow_unused=True)
+                accumulate(grads[:-1])
+                if grads[-1] is not None:
+                    g_table += grads[-1]
+            accumulate(torch.autograd.grad(table_graph, loc, g_table, allow_unused=True))
+        return (None, *total)
