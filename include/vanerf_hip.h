@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define VANERF_ABI_VERSION 5
+#define VANERF_ABI_VERSION 6
 
 #define VANERF_OK 0
 #define VANERF_EINVAL (-22)
@@ -162,6 +162,9 @@ typedef struct {
     const float* vsort;        /* [nvc*CL][4] Morton-sorted vertices (xyz, original index as int bits), padded with far points */
     const float* vbox;         /* [nvc][6]    AABB of each cluster of CL vertices */
     int nvc;
+    const float* cdisc;        /* [nc][8]  cylinder around each triangle cluster: (centre xyz, radius), (unit axis xyz, half height); the axis may be 0
+                                *           (then radius alone bounds the distance from the centre: a ball).  Every vertex of the cluster's triangles
+                                *           lies inside; second lower bound of the tile search of vanerf_mesh_query_accel (ray-grid hint) */
 } VanerfMeshAccel;
 
 /* knn_idx (may be NULL): 1-NN vertex of every point (knn_points K=1, src/networks.py:28), found in the same pass.

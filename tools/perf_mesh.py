@@ -14,7 +14,7 @@ sdd = {k: v.cuda() for k, v in sd.items() if k.startswith("tex_vis_fusion.")}
 fdat = R.FrameData(sdd, fd["img_in"], fd["feat_geo"], fd["feat_tex"], fd["src_foreground_mask"], fd["cam_in"], fd["targets"], fd["sp_data"])
 rays = R.ray_setup(frame["cam_tar"], frame["bounds"], 0, 0, 1, 334, 512, 64, device="cuda")
 pts = R.sample_points(rays["rays_d"], rays["cam_pos"], rays["z"])
-for grid in ((334, 512, 64), None):
+for grid in ((334, 512, 64),) if "--hint-only" in sys.argv else ((334, 512, 64), None):
     ts = []
     for _ in range(4):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -39,4 +39,4 @@ if "--phases" in sys.argv:  # needs VANERF_HIPCC_FLAGS=-DVANERF_MESH_PHASES
     nw = pts.shape[0] / 64
     print(f"  per wave of 64 points (per-lane search): {buf[5] / nw:.1f} clusters pass the wave-level test, {buf[6] / nw:.1f} are opened by some lane, {buf[7] / nw:.1f} exact evaluations")
     nt = max(1, buf[8])
-    print(f"  closest face: {buf[8]} waves by the tile search ({buf[10] / nt:.0f} cycles each up to here, {buf[12] / nt:.1f} clusters listed, {buf[11] / nt:.1f} per-lane evaluations), {buf[9]} waves by the per-lane search")
+    print(f"  closest face: {buf[8]} waves by the tile search ({buf[10] / nt:.0f} cycles each up to here, {buf[12] / nt:.1f} clusters listed, {buf[11] / nt:.1f} per-lane evaluations), {buf[9]} waves by the per-lane search (tile too wide: {buf[13]}, cluster list full: {buf[14]}, candidate table full: {buf[15]})")

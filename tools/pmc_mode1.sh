@@ -6,7 +6,7 @@ set -u
 MODE=${1:-1}; OUT=${2:-gpurun_out/pmc_mode$MODE}
 ROOT=$(pwd); mkdir -p "$OUT"; export TMPDIR=/tmp
 TOOL=${PMC_TOOL:-tools/perf_query.py}
-if [ "$TOOL" = "tools/perf_query.py" ]; then ARGS="--iters 2 --mode $MODE"; else ARGS=""; fi
+if [ "$TOOL" = "tools/perf_query.py" ]; then ARGS="--iters 2 --mode $MODE"; else ARGS="--hint-only"; fi
 pass() { n=$1; shift; echo "pass $n: $*"; (cd /tmp && timeout -k 10 150 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$ROOT/$OUT/p$n" -- python3 "$ROOT/$TOOL" $ARGS > "$ROOT/$OUT/p$n.log" 2>&1) || echo "pass $n failed"; }
 pass 1 SQ_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE
 pass 2 SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_SALU

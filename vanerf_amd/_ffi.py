@@ -12,7 +12,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int64, c_uint
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VANERF_HIP_LIB") or os.path.join(_HERE, "lib", "libvanerf_hip.so")  # the override is for A/B runs of kernel builds (tools/)
-ABI_VERSION = 5
+ABI_VERSION = 6
 NUM_LAYERS = 20
 
 if not os.path.exists(LIB_PATH):
@@ -49,7 +49,7 @@ class VanerfMeshAccel(Structure):
     _fields_ = [
         ("tri", _FP), ("sphere", _FP), ("tnorm", _FP), ("orig", _FP), ("cbox", _FP), ("nfp", c_int), ("nc", c_int),
         ("cell_start", _FP), ("cell_tri", _FP), ("G", c_int), ("y0", c_float), ("z0", c_float), ("cell_y", c_float), ("cell_z", c_float),
-        ("vsort", _FP), ("vbox", _FP), ("nvc", c_int),
+        ("vsort", _FP), ("vbox", _FP), ("nvc", c_int), ("cdisc", _FP),
     ]
 
 

@@ -557,7 +557,29 @@ __global__ __launch_bounds__(MA_BLOCK) void mesh_query_accel_kernel(const Vanerf
             if (lane < CL) { const Tri T = load_tri(cseed * CL + lane); U = point_tri_dist2(tc, T.a, T.b, T.c); }
             U = wave_min(U);
             const float thr = sq_plus(U);
-            const int ns = collect(s_box, A.nc, thr);
+            // clusters within thr of tc by BOTH lower bounds: the axis-aligned box (LDS) and the cylinder around the cluster (axis = mean normal
+            // through the mean vertex; global table, one cluster per lane).  For a tile centimetres from the mesh the box alone is too loose --
+            // a corner of it sticks out towards the tile by up to half its diagonal -- and lists every cluster of the near side.
+            int ns = 0;
+            for (int c0 = 0; c0 < A.nc; c0 += 64) {
+                const int cl_ = min(c0 + lane, A.nc - 1);
+                bool keep = c0 + lane < A.nc && box_dist2(tc, s_box + 6 * cl_) <= thr;
+                if (keep) {
+                    const float4 cd = reinterpret_cast<const float4*>(A.cdisc)[2 * cl_], cn = reinterpret_cast<const float4*>(A.cdisc)[2 * cl_ + 1];
+                    const f3 e = {tc.x - cd.x, tc.y - cd.y, tc.z - cd.z};
+                    const float L2 = dot3(e, e), h = (cn.x * e.x + cn.y * e.y) + cn.z * e.z;
+                    const float dh = fmaxf(fabsf(h) * (1.0f - 1e-5f) - cn.w, 0.0f), dl = fmaxf(sqrtf(fmaxf(L2 - h * h, 0.0f)) * (1.0f - 1e-5f) - cd.w, 0.0f);
+                    keep = (dh * dh + dl * dl) * (1.0f - 1e-5f) <= thr;
+                }
+                const unsigned long long m = __ballot(keep);
+                const int pos = ns + mbcnt(m);
+                if (keep && pos < TL_LIST) my_list[pos] = (unsigned short)cl_;
+                ns += __builtin_popcountll(m);
+            }
+            __builtin_amdgcn_wave_barrier();
+#ifdef VANERF_MESH_PHASES
+            if (lane == 0 && ns > TL_LIST) ph[14] += 1; // list overflow
+#endif
             if (ns > TL_LIST) return false;
 #ifdef VANERF_MESH_PHASES
             if (lane == 0) ph[12] += ns; // clusters on the list
@@ -623,6 +645,9 @@ __global__ __launch_bounds__(MA_BLOCK) void mesh_query_accel_kernel(const Vanerf
                     K += __builtin_popcountll(m);
                 }
             }
+#ifdef VANERF_MESH_PHASES
+            if (lane == 0 && K > TL_CAND) ph[15] += 1; // candidate table overflow
+#endif
             if (K > TL_CAND) return false;
             __builtin_amdgcn_wave_barrier();
 #ifdef VANERF_MESH_PHASES
@@ -656,6 +681,7 @@ __global__ __launch_bounds__(MA_BLOCK) void mesh_query_accel_kernel(const Vanerf
         }
         const bool tiled = try_tile && face_tile(cseed);
 #ifdef VANERF_MESH_PHASES
+        if (lane == 0 && !try_tile) ph[13] += 1;
         if (lane == 0) { ph[tiled ? 8 : 9] += 1; const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (tiled) ph[10] += t_ - tprev; }
 #endif
         if (!tiled) { best = INFINITY; bf = 0x7fffffff; eval_cluster(cseed); }
@@ -785,7 +811,7 @@ extern "C" int vanerf_mesh_query_accel(const VanerfMeshAccel* accel, const float
         if (n == 0) return; // an empty batch is valid (and has null data pointers)
         if (!accel || !verts || !faces || !vert_vis || !pts || !sdf || !vis) throw_error("vanerf_mesh_query_accel: null argument");
         const VanerfMeshAccel& A = *accel;
-        if (!A.tri || !A.sphere || !A.tnorm || !A.orig || !A.cbox || !A.cell_start || !A.cell_tri) throw_error("vanerf_mesh_query_accel: accel has a null pointer");
+        if (!A.tri || !A.sphere || !A.tnorm || !A.orig || !A.cbox || !A.cdisc || !A.cell_start || !A.cell_tri) throw_error("vanerf_mesh_query_accel: accel has a null pointer");
         if (A.nc <= 0 || A.nc > MA_MAX_CLUSTERS || A.nfp != A.nc * CL || A.nfp < nf) throw_error("vanerf_mesh_query_accel: bad cluster table (nc=%d nfp=%d nf=%d)", A.nc, A.nfp, nf);
         if (A.G <= 0 || !(A.cell_y > 0.0f) || !(A.cell_z > 0.0f)) throw_error("vanerf_mesh_query_accel: bad grid");
         if (nv <= 0 || nf <= 0 || n < 0) throw_error("vanerf_mesh_query_accel: nv=%d nf=%d n=%lld", nv, nf, (long long)n);

@@ -218,6 +218,17 @@ class MeshAccel:
         self.tnorm = torch.cat([unit, (1e5 * a_t * a_t)[:, None]], 1).contiguous()
         cl = tri_s.reshape(nfp // self.CL, self.CL * 3, 3)
         self.cbox = torch.cat([cl.min(1)[0], cl.max(1)[0]], 1).contiguous()
+        # cylinder around each cluster (tile search): centre = mean vertex, axis = normalised sum of the triangles' area normals, radius /
+        # half height = the largest lateral / axial offset of a vertex, padded by the fp32 error of the products (1e-5 relative + a_t)
+        ccen = cl.mean(1)
+        cax = nrm.reshape(nfp // self.CL, self.CL, 3).sum(1)
+        cal = cax.norm(dim=-1, keepdim=True)
+        cax = torch.where(cal > 1e-20, cax / cal.clamp_min(1e-30), torch.zeros_like(cax))
+        off = cl - ccen[:, None]
+        hh = (off * cax[:, None]).sum(-1)
+        lat = (off.pow(2).sum(-1) - hh.pow(2)).clamp_min(0).sqrt()
+        pad = a_t.reshape(nfp // self.CL, self.CL).amax(1)
+        self.cdisc = torch.cat([ccen, (lat.amax(1) * (1.0 + 1e-5) + pad)[:, None], cax, (hh.abs().amax(1) * (1.0 + 1e-5) + pad)[:, None]], 1).contiguous()
         # (y,z) grid: cell index = clamp(floor((c - c0) / cell), 0, G-1) -- the SAME fp32 expression as the kernel, so the
         # monotone map sends every point of a triangle's (y,z) bounding box into the triangle's cell range
         G = int(grid)
@@ -254,7 +265,7 @@ class MeshAccel:
         c = VanerfMeshAccel()
         c.vsort, c.vbox, c.nvc = _ptr(self.vsort, f32), _ptr(self.vbox, f32), nvp // self.CL
         c.tri, c.sphere, c.orig, c.cbox = _ptr(self.tri, f32), _ptr(self.sphere, f32), _ptr(self.orig, torch.int32), _ptr(self.cbox, f32)
-        c.tnorm = _ptr(self.tnorm, f32)
+        c.tnorm, c.cdisc = _ptr(self.tnorm, f32), _ptr(self.cdisc, f32)
         c.nfp, c.nc = nfp, nfp // self.CL
         c.cell_start, c.cell_tri = _ptr(self.cell_start, torch.int32), _ptr(self.cell_tri, torch.int32)
         c.G, c.y0, c.z0, c.cell_y, c.cell_z = G, y0, z0, cell_y, cell_z
