@@ -217,8 +217,10 @@ def main():
         from vanerf_amd.parallel import deinterleave, rank_rows
         full_img = deinterleave(img, H, W, world)
         own = step()
-        own = own.view(world, rows[2], W, 3)[rank] if own.shape[0] == H * W else own.view(rows[2], W, 3)
-        assert torch.equal(full_img[rank_rows(H, world, rank).to(full_img.device)], own), "gathered image does not contain this rank's rows"
+        own = own.view(world, rows[2], W, 3)[rank]
+        rr = rank_rows(H, world, rank)
+        keep = rr < H  # (a height that is not a multiple of 8 * world is padded below the image)
+        assert torch.equal(full_img[rr[keep].to(full_img.device)], own[keep.to(own.device)]), "gathered image does not contain this rank's rows"
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:

@@ -59,22 +59,24 @@ def test_two_rank_gather():
 
 
 def test_shard_rows_cover_image_once():
-    for height in (512, 16, 12):  # 12 rows on 4 ranks: not a multiple of 8 * world -> single interleaved rows
-        for world in (1, 2, 4, 8):
-            if height % world:
-                continue
+    for height in (512, 16, 12, 500, 334, 7):  # heights that are not a multiple of 8 * world are padded below the image
+        for world in (1, 2, 3, 4, 8):
             seen = torch.zeros(height, dtype=torch.int32)
+            sizes = set()
             for rank in range(world):
                 y0, step, ny, yb = shard_rows(height, world, rank)
-                assert ny == height // world and yb in (1, 8)
-                seen[rank_rows(height, world, rank)] += 1
-            assert (seen == 1).all()
+                assert yb == 8 and ny % 8 == 0
+                sizes.add(ny)
+                rows = rank_rows(height, world, rank)
+                seen[rows[rows < height]] += 1
+            assert (seen == 1).all() and len(sizes) == 1  # every image row once, equal tiles
     # blocks of 8 rows stay together (8x8 pixel tiles of the mesh query), dealt round robin
     assert rank_rows(512, 8, 3)[:10].tolist() == [24, 25, 26, 27, 28, 29, 30, 31, 88, 89]
-    for hh, world in ((H, 2), (12, 4), (64, 4)):
-        img = torch.arange(hh * W * 3, dtype=torch.float32).view(hh, W, 3)
+    for hh, world in ((H, 2), (12, 4), (64, 4), (500, 8), (30, 3)):
+        hp = max(int(rank_rows(hh, world, r).max()) for r in range(world)) + 1
+        img = torch.arange(hp * W * 3, dtype=torch.float32).view(hp, W, 3)  # the padding rows hold something too
         tiles = [img[rank_rows(hh, world, r)].reshape(-1, 3) for r in range(world)]
-        assert torch.equal(deinterleave(torch.cat(tiles, 0), hh, W, world), img)
+        assert torch.equal(deinterleave(torch.cat(tiles, 0), hh, W, world), img[:hh])
 
 
 def _grad_worker(rank, world, port, q):

@@ -12,27 +12,32 @@ import torch
 ROW_BLOCK = 8
 
 
+def padded_height(height, world):
+    """Rows that are actually rendered: the image height rounded up to whole 8-row blocks per rank (all_gather needs equal tiles).  The extra
+    rows (at most 8 * world - 1, below the image) are marched like any other -- their rays are ordinary rays of the same camera -- and cut
+    off again by deinterleave()."""
+    per = ROW_BLOCK * world
+    return (height + per - 1) // per * per
+
+
 def shard_rows(height, world, rank):
     """(y0, y_step, n_rows, y_block) of this rank's rows: row k of the rank is image row y0 + (k // y_block) * y_step + k % y_block.
-    Every rank gets the same number of rows (all_gather needs equal tiles)."""
-    if height % world != 0:
-        raise ValueError(f"image height {height} must be divisible by the number of ranks {world}")
-    yb = ROW_BLOCK if height % (ROW_BLOCK * world) == 0 else 1  # fall back to single interleaved rows
-    return rank * yb, world * yb, height // world, yb
+    Every rank gets the same number of rows; for heights that are not a multiple of 8 * world the last blocks reach below the image."""
+    return rank * ROW_BLOCK, world * ROW_BLOCK, padded_height(height, world) // world, ROW_BLOCK
 
 
 def rank_rows(height, world, rank):
-    """Image rows of `rank`, in the order it renders them (long tensor)."""
+    """Rows of `rank`, in the order it renders them (long tensor; values >= height are the padding rows)."""
     y0, y_step, ny, yb = shard_rows(height, world, rank)
     k = torch.arange(ny)
     return y0 + (k // yb) * y_step + k % yb
 
 
 def deinterleave(gathered, height, width, world, channels=3):
-    """all_gather output [rank][row_in_rank][x][c] -> image (height, width, c) (inverse of shard_rows)."""
-    yb = ROW_BLOCK if height % (ROW_BLOCK * world) == 0 else 1
-    g = gathered.view(world, height // (world * yb), yb, width, channels)          # [rank][block][row in block]
-    return g.permute(1, 0, 2, 3, 4).reshape(height, width, channels)
+    """all_gather output [rank][row_in_rank][x][c] -> image (height, width, c) (inverse of shard_rows; the padding rows are dropped)."""
+    hp = padded_height(height, world)
+    g = gathered.view(world, hp // (world * ROW_BLOCK), ROW_BLOCK, width, channels)          # [rank][block][row in block]
+    return g.permute(1, 0, 2, 3, 4).reshape(hp, width, channels)[:height]
 
 
 def gather_image(tile, height, width, world, group=None):
