@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define VANERF_ABI_VERSION 6
+#define VANERF_ABI_VERSION 7
 
 #define VANERF_OK 0
 #define VANERF_EINVAL (-22)
@@ -263,6 +263,12 @@ int64_t vanerf_render_pass_scratch(int n_rays, int Sc, int Sf, int fine, int reu
 int vanerf_render_pass(const VanerfWeights* w, const VanerfFrame* frame, const VanerfMeshAccel* accel, const float* verts, int nv,
                        const int32_t* faces, int nf, const VanerfPassDesc* desc, const VanerfPassOut* out, void* scratch, int64_t scratch_bytes,
                        void* stream);
+
+/* Training step, backward of the row gathers (bilinear taps of feat_sample, src/utils.py:136-151; nearest / twin vertex rows of KNN_vis,
+ * src/networks.py:27-33):  table[idx[i]][0..C) += w[i] * g[i][0..C)  for i < n  (w may be NULL = 1; rows outside [0, R) are ignored).
+ * All device pointers, fp32 / int32; `table` is accumulated into.  Samples outnumber rows by hundreds: the adds go through LDS-resident
+ * slices of the table instead of contended global atomics.                                                                               */
+int vanerf_scatter_add_rows(const int32_t* idx, const float* w, const float* g, int64_t n, int C, float* table, int R, void* stream);
 
 /* a3  ray_bbox_intersection (src/model.py:1496-1570) alone: bounds[6], orig[3] (host values), dirs[R][3] (device)
  *     -> near[R], far[R] (1.0 when the ray does not cross the box exactly twice), hit[R] (u8).                               */

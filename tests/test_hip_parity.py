@@ -756,3 +756,22 @@ def test_one_call_pass_equals_the_python_sequence(R, sd_full, precision):
     c = R.render_pass_c(w, fdat, cam, b, 5, 3, 16, 20, 32, 64, 64, fine=False)
     assert "color_fine" not in c and torch.equal(c["color"], R.render_pass(w, fdat, cam, b, 5, 3, 16, 20, 32, 64, 64, fine=False)["color"])
     torch.cuda.synchronize()
+
+
+def test_scatter_add_rows(R):
+    """vanerf_scatter_add_rows (backward of the row gathers of a training step) against torch.index_add_: tables of 1 024 x 64, 16 384 x 8 and
+    1 558 x 29 rows x channels, heavy index duplication, optional per-sample weights, out-of-range rows ignored, accumulation into a non-zero table."""
+    g = torch.Generator(device="cuda").manual_seed(0)
+    for rows, C, n in ((1024, 64, 300001), (16384, 8, 262144), (1558, 29, 70000), (5, 3, 17)):
+        idx = torch.randint(0, rows, (n,), device="cuda", generator=g, dtype=torch.int32)
+        idx[: n // 3] = idx[: n // 3] % max(1, rows // 50)  # a few very hot rows
+        val = torch.randn(n, C, device="cuda", generator=g)
+        w = torch.rand(n, device="cuda", generator=g)
+        for weights in (None, w):
+            base = torch.randn(rows, C, device="cuda", generator=g)
+            want = base.double().index_add(0, idx.long(), (val if weights is None else val * weights[:, None]).double())
+            got = R.scatter_add_rows(base.clone(), idx, val, weights)
+            assert (got.double() - want).abs().max() <= 1e-5 * (1.0 + want.abs().max()), (rows, C)
+    idx = torch.tensor([0, 7, -1, 5, 2], device="cuda", dtype=torch.int32)  # rows outside the table contribute nothing
+    got = R.scatter_add_rows(torch.zeros(5, 2, device="cuda"), idx, torch.ones(5, 2, device="cuda"))
+    assert got.sum().item() == 4.0 and got[0, 0].item() == 1.0 and got[2, 1].item() == 1.0  # rows 7, -1 and 5 lie outside a 5-row table

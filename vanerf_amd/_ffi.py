@@ -12,7 +12,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int64, c_uint
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VANERF_HIP_LIB") or os.path.join(_HERE, "lib", "libvanerf_hip.so")  # the override is for A/B runs of kernel builds (tools/)
-ABI_VERSION = 6
+ABI_VERSION = 7
 NUM_LAYERS = 20
 
 if not os.path.exists(LIB_PATH):
@@ -95,6 +95,7 @@ _SIGS = {
     "vanerf_render_pass_scratch": (c_int64, [c_int, c_int, c_int, c_int, c_int]),
     "vanerf_render_pass": (c_int, [c_void_p, POINTER(VanerfFrame), POINTER(VanerfMeshAccel), _FP, c_int, _FP, c_int, POINTER(VanerfPassDesc),
                                    POINTER(VanerfPassOut), _FP, c_int64, c_void_p]),
+    "vanerf_scatter_add_rows": (c_int, [_FP, _FP, _FP, c_int64, c_int, _FP, c_int, c_void_p]),
     "vanerf_ray_bbox": (c_int, [POINTER(c_float), POINTER(c_float), _FP, c_int, _FP, _FP, _FP, c_void_p]),
 }
 EXPORTS = tuple(_SIGS)

@@ -1,0 +1,82 @@
+// train_kernels.hip -- kernels of the training step's backward pass.
+//
+// vanerf_scatter_add_rows: table[idx[i]][:] += w[i] * g[i][:] for N samples -- the backward of the row gathers of the per-sample networks
+// (bilinear taps of the feature maps, reference src/utils.py:136-151; nearest / twin vertex rows, src/networks.py:27-33).  N is ~8e5 per
+// training step and the tables have 1e3..1.6e4 rows: as global atomics (torch's index_add_) every row is hit by hundreds of samples and
+// the step spent 20 ms (28 %) there.  Here a block keeps a slice of the table's channels in LDS, adds its share of the samples with LDS
+// atomics (a contended LDS atomic costs cycles, not a trip to the memory side), and flushes the slice once with global atomics.
+#include "common.h"
+
+using namespace vanerf;
+
+namespace {
+
+constexpr int SC_BLOCK = 256;
+
+// grid: (sample chunks, channel slices).  s_tab: [R][CS] floats.
+template <int CS>
+__global__ __launch_bounds__(SC_BLOCK) void scatter_rows_kernel(const int32_t* __restrict__ idx, const float* __restrict__ w, const float* __restrict__ g,
+                                                                long long n, int C, int R, float* __restrict__ table)
+{
+    extern __shared__ float s_tab[];
+    const int c0 = blockIdx.y * CS;
+    for (int k = threadIdx.x; k < R * CS; k += SC_BLOCK) s_tab[k] = 0.0f;
+    __syncthreads();
+    const int cl = threadIdx.x % CS;        // channel within the slice
+    const int sub = threadIdx.x / CS;       // sample within a step of SC_BLOCK / CS samples
+    constexpr int PER = SC_BLOCK / CS;
+    const long long chunk = (n + gridDim.x - 1) / gridDim.x;
+    const long long i0 = (long long)blockIdx.x * chunk, i1 = i0 + chunk < n ? i0 + chunk : n;
+    if (c0 + cl < C)
+        for (long long i = i0 + sub; i < i1; i += PER) {
+            const int r = idx[i];
+            if ((unsigned)r >= (unsigned)R) continue; // an index outside the table contributes nothing (the forward gather would have faulted)
+            float v = g[i * C + c0 + cl];
+            if (w) v *= w[i];
+            atomicAdd(&s_tab[r * CS + cl], v);
+        }
+    __syncthreads();
+    for (int k = threadIdx.x; k < R * CS; k += SC_BLOCK) {
+        const float v = s_tab[k];
+        const int c = c0 + k % CS;
+        if (v != 0.0f && c < C) atomicAdd(&table[(size_t)(k / CS) * C + c], v);
+    }
+}
+
+} // namespace
+
+// table[R][C] += scatter of w[i] * g[i][C] at rows idx[i] (w may be NULL = 1).  All device pointers; `table` is accumulated into (zero it first
+// for a plain gradient).  Rows outside [0, R) are ignored.
+extern "C" int vanerf_scatter_add_rows(const int32_t* idx, const float* w, const float* g, int64_t n, int C, float* table, int R, void* stream)
+{
+    return guarded([&] {
+        if (n == 0) return;
+        if (!idx || !g || !table) throw_error("vanerf_scatter_add_rows: null argument");
+        if (n < 0 || C <= 0 || R <= 0) throw_error("vanerf_scatter_add_rows: n=%lld C=%d R=%d", (long long)n, C, R);
+        // channel slice: the widest power of two <= 16 whose [R][CS] floats fit 128 KB of LDS
+        int cs = 16;
+        while (cs > 1 && ((size_t)R * cs * 4 > 128 * 1024 || cs / 2 >= C)) cs /= 2;
+        if ((size_t)R * cs * 4 > 128 * 1024) throw_error("vanerf_scatter_add_rows: a table of %d rows does not fit the LDS slice", R);
+        const int slices = (C + cs - 1) / cs;
+        int chunks = (int)((n + 4095) / 4096);
+        if (chunks > 1024 / slices) chunks = 1024 / slices > 0 ? 1024 / slices : 1;
+        if (chunks < 1) chunks = 1;
+        const size_t lds = (size_t)R * cs * 4;
+        const dim3 grid((unsigned)chunks, (unsigned)slices);
+        const hipStream_t st = (hipStream_t)stream;
+#define LAUNCH(CS)                                                                                                                         \
+    do {                                                                                                                                   \
+        if (lds > 64 * 1024) HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(scatter_rows_kernel<CS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL(scatter_rows_kernel<CS>, grid, dim3(SC_BLOCK), lds, st, idx, w, g, (long long)n, C, R, table);                  \
+    } while (0)
+        switch (cs) {
+        case 16: LAUNCH(16); break;
+        case 8: LAUNCH(8); break;
+        case 4: LAUNCH(4); break;
+        case 2: LAUNCH(2); break;
+        default: LAUNCH(1); break;
+        }
+#undef LAUNCH
+        HIP_CHECK(hipGetLastError());
+    });
+}

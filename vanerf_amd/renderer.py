@@ -688,3 +688,12 @@ def render_pass_c(weights, frame, cam_tar, bounds, x0, y0, step, nx, ny, sample_
     check(lib.vanerf_render_pass(weights.handle, byref(frame.c), byref(frame.accel.c), _ptr(frame.verts3, f32), frame.verts3.shape[0],
                                  _ptr(frame.faces, torch.int32), frame.faces.shape[0], byref(d), byref(o), _ptr(scratch), nbytes, _stream()))
     return out
+
+
+def scatter_add_rows(table, idx, g, w=None):
+    """table[idx[i]] += w[i] * g[i] (vanerf_scatter_add_rows): the backward of a row gather over ~1e6 samples into a table of ~1e3..1e4 rows."""
+    n, C = g.shape
+    assert table.shape[1] == C and idx.shape == (n,) and table.is_contiguous()
+    check(lib.vanerf_scatter_add_rows(_ptr(idx, torch.int32), _ptr(w, torch.float32), _ptr(g.contiguous(), torch.float32), n, C,
+                                      _ptr(table, torch.float32), table.shape[0], _stream()))
+    return table

@@ -19,11 +19,54 @@ import torch.nn.functional as F
 NUM_V = 779  # vertices per hand: the "other hand" twin of vertex i is (i + 779) mod 1558 (src/networks.py:30-32)
 
 
+def _scatter_rows(n_rows, idx32, g, w=None):
+    """sum over samples of w[i] g[i] into row idx[i] of a zero (n_rows, C) table: vanerf_scatter_add_rows (LDS-resident table slices; as
+    torch's index_add_ -- contended global atomics, hundreds of samples per row -- this was 20 ms of a 73 ms step)."""
+    from . import renderer as R
+    return R.scatter_add_rows(torch.zeros(n_rows, g.shape[1], dtype=torch.float32, device=g.device), idx32, g.contiguous(), w)
+
+
+class _Rows(torch.autograd.Function):
+    """table.index_select(0, idx) with the HIP scatter as its backward."""
+
+    @staticmethod
+    def forward(ctx, table, idx64, idx32):
+        ctx.save_for_backward(idx32)
+        ctx.n_rows = table.shape[0]
+        return table.index_select(0, idx64)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _scatter_rows(ctx.n_rows, ctx.saved_tensors[0], g), None, None
+
+
+class _Bilinear(torch.autograd.Function):
+    """Four-tap blend of rows of a channel-last map; backward: four weighted scatters (the tap weights ride along in the kernel)."""
+
+    @staticmethod
+    def forward(ctx, rows, i64, i32, wx, wy):
+        ctx.save_for_backward(i32, wx, wy)
+        ctx.n_rows = rows.shape[0]
+        t = [rows.index_select(0, i64[k]) for k in range(4)]
+        return (t[0] * (1.0 - wx) + t[1] * wx) * (1.0 - wy) + (t[2] * (1.0 - wx) + t[3] * wx) * wy
+
+    @staticmethod
+    def backward(ctx, g):
+        i32, wx, wy = ctx.saved_tensors
+        from . import renderer as R
+        g = g.contiguous()
+        out = torch.zeros(ctx.n_rows, g.shape[1], dtype=torch.float32, device=g.device)
+        ws = ((1.0 - wx) * (1.0 - wy), wx * (1.0 - wy), (1.0 - wx) * wy, wx * wy)
+        for k in range(4):
+            R.scatter_add_rows(out, i32[k], g, ws[k].reshape(-1).contiguous())
+        return out, None, None, None, None
+
+
 def sample_map(feat, xy):
     """feat_sample (src/utils.py:136-151): (1,C,H,W) map at (N,2) coordinates in [-1,1] -> (N,C); bilinear, border, align_corners.
     Written as four row gathers from the channel-last map: the coordinates carry no gradient here, and the backward of a row gather is
-    an index_add of contiguous C-float rows, where grid_sampler_2d_backward issues one strided atomic per channel and tap (4.2 ms per
-    call on the 64-channel map, a quarter of the training step)."""
+    a scatter-add of contiguous C-float rows (vanerf_scatter_add_rows), where grid_sampler_2d_backward issues one strided atomic per
+    channel and tap (4.2 ms per call on the 64-channel map)."""
     _, C, H, W = feat.shape
     with torch.no_grad():
         x = ((xy[:, 0] + 1.0) * (0.5 * (W - 1))).clamp(0.0, W - 1.0)
@@ -32,21 +75,58 @@ def sample_map(feat, xy):
         wx, wy = (x - x0)[:, None], (y - y0)[:, None]
         x0, y0 = x0.long(), y0.long()
         x1, y1 = (x0 + 1).clamp(max=W - 1), (y0 + 1).clamp(max=H - 1)
+        i64 = torch.stack([y0 * W + x0, y0 * W + x1, y1 * W + x0, y1 * W + x1])
     rows = feat[0].permute(1, 2, 0).reshape(H * W, C)
-    tap = lambda yy, xx: rows.index_select(0, yy * W + xx)
-    return (tap(y0, x0) * (1.0 - wx) + tap(y0, x1) * wx) * (1.0 - wy) + (tap(y1, x0) * (1.0 - wx) + tap(y1, x1) * wx) * wy
+    if not (rows.is_cuda and rows.requires_grad):
+        tap = lambda k: rows.index_select(0, i64[k])
+        return (tap(0) * (1.0 - wx) + tap(1) * wx) * (1.0 - wy) + (tap(2) * (1.0 - wx) + tap(3) * wx) * wy
+    return _Bilinear.apply(rows, i64, i64.to(torch.int32), wx, wy)
+
+
+class _Linear(torch.autograd.Function):
+    """y = x W^T + b over N samples (N ~ 8e5 in a training step) with a backward that keeps the whole chip busy: the weight gradient
+    dW = dY^T X is a reduction over N into a tiny (out x in) matrix, which the GEMM library tiles by OUTPUT (48 workgroups for 128 x 358, on
+    256 CUs: 17 TFLOP/s fp32, 39 % of the step); here the reduction is cut into 64 slices (one batched GEMM, 3 072 workgroups) that are
+    summed afterwards."""
+
+    SLICES = 64
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        return F.linear(x, w, b)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        g = g.contiguous()
+        gx = g @ w if ctx.needs_input_grad[0] else None
+        gw = None
+        if ctx.needs_input_grad[1]:
+            n, S = x.shape[0], _Linear.SLICES
+            per = n // S
+            if per >= 256:
+                head = per * S
+                gw = torch.bmm(g[:head].view(S, per, -1).transpose(1, 2), x[:head].view(S, per, -1)).sum(0)
+                if head < n:
+                    gw = gw + g[head:].t() @ x[head:]
+            else:
+                gw = g.t() @ x
+        gb = g.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        return gx, gw, gb
 
 
 def _linear_wn(P, prefix, x):
     """Linear of MLPUNetFusion (src/utils.py:670-685): weight-normed, W = g v / ||v||_row, except the last layer of each stack."""
     if prefix + ".weight_v" in P:
         v, g = P[prefix + ".weight_v"], P[prefix + ".weight_g"]
-        return F.linear(x, v * (g / v.norm(2, dim=1, keepdim=True)), P[prefix + ".bias"])
-    return F.linear(x, P[prefix + ".weight"], P[prefix + ".bias"])
+        return _Linear.apply(x, v * (g / v.norm(2, dim=1, keepdim=True)), P[prefix + ".bias"])
+    return _Linear.apply(x, P[prefix + ".weight"], P[prefix + ".bias"])
 
 
 def _conv1(P, key, x):
-    return F.linear(x, P[key][:, :, 0])  # bias-free Conv1d(k = 1) on (N,C)
+    return _Linear.apply(x, P[key][:, :, 0], None)  # bias-free Conv1d(k = 1) on (N,C)
 
 
 def _softplus(x):
@@ -87,8 +167,9 @@ def _nearest_rows(table, vis, idx):
     """KNN_vis (src/networks.py:27-33) with the nearest-vertex index given: rows of the nearest vertex and of its twin, x visibility."""
     twin = (idx + NUM_V) % (2 * NUM_V)
     vi, vt = vis[idx, None], vis[twin, None]
-    # index_select: its backward is an index_add (atomics); table[idx] goes through a sort-based index_put (3.4 ms per call, 12 calls a step)
-    return table.index_select(0, idx) * vi, table.index_select(0, twin) * vt, vi, vt
+    if not (table.is_cuda and table.requires_grad):
+        return table.index_select(0, idx) * vi, table.index_select(0, twin) * vt, vi, vt
+    return _Rows.apply(table, idx, idx.to(torch.int32)) * vi, _Rows.apply(table, twin, twin.to(torch.int32)) * vt, vi, vt
 
 
 def geo_fusion(P, geo_maps, pix, vert_xy, idx, vert_vis, q_vis, q_sdf, pre="geo_vis_fusion."):
@@ -176,7 +257,7 @@ def networks_at(P, frame, pts, q_sdf, q_vis, knn, noise=None, sp_args=None):
     fused = geo_fusion(P, frame["feat_geo"], pix, vert_xy, knn, vis, qv, qs)
     pe = positional_encoding(pts, frame["kpt3d"], frame["extrin"], sp["sp_level"], sp["scale"], sp["sigma"])
     geo, latent = geometry_mlp(P, pe, fused, weight)
-    latent24 = F.linear(latent, P["ibr_compress_gfeat.weight"], P["ibr_compress_gfeat.bias"])
+    latent24 = _Linear.apply(latent, P["ibr_compress_gfeat.weight"], P["ibr_compress_gfeat.bias"])
     table29 = frame.get("table29")
     if table29 is None:
         table29 = texture_vertex_table(P, vert_xy, frame["feat_tex"], frame["img"])
@@ -206,8 +287,8 @@ def straight_through(value, graph):
 
 # Rays per chunk of the backward pass (PassGradient); None = the whole patch at once.  The graph of a chunk lives only while its gradient is
 # taken, so chunking bounds the step's peak memory -- at the price of launch-bound kernels.  Measured on the 64x64 patch at 64 + 64 samples
-# (786 k samples, tools/perf_train_step.py, one MI355X): whole patch 97 ms / 10.2 GiB, 2048 rays 115 ms / 5.4 GiB, 1024 rays 155 ms /
-# 3.0 GiB, 512 rays 186 ms / 1.9 GiB.  With 288 GB of HBM the default is speed; model config key `grad_rays_per_chunk` sets it.
+# (786 k samples, tools/perf_train_step.py, one MI355X, before the split-K / scatter kernels below took the whole-patch step from 97 to 62 ms):
+# whole patch 97 ms / 10.2 GiB, 2048 rays 115 ms / 5.4 GiB, 1024 rays 155 ms / 3.0 GiB, 512 rays 186 ms / 1.9 GiB.  With 288 GB of HBM the default is speed; model config key `grad_rays_per_chunk` sets it.
 # (bf16 operands for this graph's GEMMs were measured too: 106 ms, and the parameter gradients moved by 4e-2 relative -- dropped.)
 GRAD_RAYS_PER_CHUNK = None
 
