@@ -171,6 +171,13 @@ __device__ __forceinline__ void run_layer(f32x16 (&acc)[NB], Ring<NB>& ring, WRs
 // ring depths (steps in flight) for layers with 4/3, 1 and 2 output blocks.  With the pinned software pipeline of run_layer_b, measured in
 // one session: (2,4,2) 8.16-8.23 ms, (2,3,2) 8.22, (2,2,2) 8.24, (1,4,2) 8.25, (3,6,3) 8.32, (1,2,1) 8.33, (4,8,4) +4 %, (5,8,4) +8 %:
 // two k-steps ahead cover the L2 latency, deeper rings only add loads in flight
+// experiment knobs: bit L set = layer L runs with one product (W_hi X_hi) / two products (W_hi X_hi + W_lo X_hi: activations rounded to bf16)
+#ifndef VANERF_P1_MASK
+#define VANERF_P1_MASK 0
+#endif
+#ifndef VANERF_P2_MASK
+#define VANERF_P2_MASK 0
+#endif
 #ifndef VANERF_CHUNKS
 #define VANERF_CHUNKS 4
 #endif
@@ -252,7 +259,7 @@ struct NoPre { template <class C> __device__ __forceinline__ void operator()(C) 
 // So: step s's MFMAs are cut into four chunks, after each chunk comes one pair-split of step s+1's operands (5 VALU), the re-load of
 // the consumed ring slot is issued before the first chunk, and a sched_barrier(0) after every chunk keeps that order.
 // (sched_group_barrier could request the same interleave, but its solver did not finish on this 10 k-instruction block in 15 min.)
-template <int NB, int T, bool RES = false, class Op, class Pre = NoPre>
+template <int NB, int T, bool RES = false, int PRODS = 3, class Op, class Pre = NoPre>
 __device__ __forceinline__ void run_layer_b(f32x16 (&acc)[NB], RingB<NB>& ring, WRsrc rs, unsigned sbase_dw, unsigned vb, Op&& operand,
                                             Pre&& pre = Pre{})
 {
@@ -270,7 +277,7 @@ __device__ __forceinline__ void run_layer_b(f32x16 (&acc)[NB], RingB<NB>& ring, 
         unsigned hpk = pack_bf16(x0, x1);
         asm("" : "+v"(hpk));
         bh[i] = hpk;
-        bl[i] = pack_bf16(x0 - __uint_as_float(hpk << 16), x1 - __uint_as_float(hpk & 0xffff0000u));
+        if constexpr (PRODS == 3) bl[i] = pack_bf16(x0 - __uint_as_float(hpk << 16), x1 - __uint_as_float(hpk & 0xffff0000u));
     };
     u32x4 bh, bl;
     pre(std::integral_constant<int, 0>{});
@@ -287,7 +294,7 @@ __device__ __forceinline__ void run_layer_b(f32x16 (&acc)[NB], RingB<NB>& ring, 
             constexpr int c = decltype(cc)::value;
             static_for<3 * NB>([&](auto mc) {
                 constexpr int m = decltype(mc)::value, ob = m / 3, pr = m % 3;
-                if constexpr (m * NCH / (3 * NB) == c) {
+                if constexpr (m * NCH / (3 * NB) == c && (pr == 0 || (pr == 1 && PRODS == 3) || (pr == 2 && PRODS >= 2))) {
                     const bf16x8 wh = __builtin_bit_cast(bf16x8, a.hi[ob]), wl = __builtin_bit_cast(bf16x8, a.lo[ob]);
                     acc[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pr == 2 ? wl : wh, pr == 1 ? xl : xh, acc[ob], 0, 0, 0);
                 }
@@ -316,7 +323,7 @@ template <int MODE, int NB, int T, int L, class Op>
 __device__ __forceinline__ void run_layer_m(f32x16 (&acc)[NB], typename RingSel<MODE, NB>::type& ring, WRsrc rs, int lane, Op&& operand)
 {
     if constexpr (MODE == 0) run_layer<NB, T>(acc, ring, rs, layer_offset(L), (unsigned)lane * NB * 4u, static_cast<Op&&>(operand));
-    else run_layer_b<NB, T, (L >= LDS_FIRST)>(acc, ring, rs, layer_offset_b(L), (unsigned)lane * 16u, static_cast<Op&&>(operand));
+    else run_layer_b<NB, T, (L >= LDS_FIRST), (((VANERF_P1_MASK >> L) & 1) ? 1 : ((VANERF_P2_MASK >> L) & 1) ? 2 : 3)>(acc, ring, rs, layer_offset_b(L), (unsigned)lane * 16u, static_cast<Op&&>(operand));
 }
 
 template <int NB> __device__ __forceinline__ void zero(f32x16 (&acc)[NB])
@@ -735,7 +742,7 @@ __global__ __launch_bounds__(BLOCK, MODE == 1 ? VANERF_WAVES_PER_SIMD_B : VANERF
                         // 179 the bias.  A bf16 step takes 8 consecutive pairs, so key point i is computed right before the first step
                         // that needs it (at most two key points are live at a time).
                         float feat[PE_KPT_PER_HALF][PE_FEATS];
-                        run_layer_b<4, 180, false>(a0, ring0b, W, layer_offset_b(L_MLP0), (unsigned)lane * 16u,
+                        run_layer_b<4, 180, false, (((VANERF_P1_MASK >> L_MLP0) & 1) ? 1 : ((VANERF_P2_MASK >> L_MLP0) & 1) ? 2 : 3)>(a0, ring0b, W, layer_offset_b(L_MLP0), (unsigned)lane * 16u,
                             [&](auto tc) -> float {
                                 constexpr int t = decltype(tc)::value;
                                 if constexpr (t < 147) return feat[t / 7][t % 7];
