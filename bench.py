@@ -212,6 +212,15 @@ def main():
         err = (got - want).abs()
         result["parity"] = {"psnr_db": orc.psnr(got, want), "max_abs_err": err.max().item(),
                             "frac_pixels_above_1e-4": (err.max(1)[0] > 1e-4).float().mean().item(), "pixels": int(idx.numel())}
+        # the same pixels once more with the oracle's own rays and depths injected (identical sample positions on both sides): what is left of
+        # the difference when the ray generator's last bit is taken out (tests/test_hip_injected.py holds this to 1e-4 with no allowance)
+        px = grids[0].to(torch.int32).cuda().contiguous()
+        inj = {"rays_d": ref["cam_rays"][0].contiguous().cuda(), "cam_pos": ref["cam_pos"].reshape(3).contiguous().cuda(),
+               "z": ref["z"][0].contiguous().cuda(), "z_fine": ref["z_fine"][0].contiguous().cuda()}
+        oi = renderer.render_pass(weights, fdat, frame["cam_tar"], frame["bounds"], 0, 0, 1, px.shape[0], 1, S, S, pixels=px, inject=inj)
+        erri = (oi["color_fine"].cpu() - want).abs()
+        result["parity"].update({"max_abs_err_same_rays": erri.max().item(), "frac_pixels_above_1e-4_same_rays": (erri.max(1)[0] > 1e-4).float().mean().item(),
+                                 "note": "first three figures: the timed image (HIP ray generator) vs the oracle; *_same_rays: the oracle's rays and depths injected"})
         result["speedup_vs_cpu"] = result["value"] / base["value"]
     if world > 1:  # the gathered, de-interleaved image must contain this rank's own rows at their place
         from vanerf_amd.parallel import deinterleave, rank_rows
