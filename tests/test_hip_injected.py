@@ -134,6 +134,15 @@ def test_config3_128_samples_on_16x16_rays(R, sd_full, precision):
         print(f"config 3 [{precision}] own rays {gk}: {bad}/768 elements above 1e-4 (max {err:.2e}): flips behind last-bit differences of the ray generator")
     for k in ("depth", "alpha", "depth_fine", "alpha_fine"):
         assert_close_frac(own[k].cpu().view(n, n), ref[k][0], TOL, 3e-2, k)
+    # the full-size shape of config 3 (512x334 rays, 128 + 128 samples: 43.8 M fine samples in one pass) through the C entry point: rays are
+    # independent, so the 256 rays above are bit-for-bit the full view's values at their pixels -- which ties the whole view to the oracle
+    full = R.render_pass_c(w, fdat, frame["cam_tar"], frame["bounds"], 0, 0, 1, 334, 512, 128, 128)
+    torch.cuda.synchronize()
+    assert torch.equal(full["index"].cpu(), torch.arange(334 * 512)) and torch.isfinite(full["color_fine"]).all()
+    assert (full["z_fine"][:, 1:] >= full["z_fine"][:, :-1]).all()
+    at = own["index"]
+    for k in ("color", "depth", "alpha", "color_fine", "depth_fine", "alpha_fine", "sdf", "z_fine"):
+        assert torch.equal(full[k][at], own[k]), k
 
 
 def _train_case(golden):

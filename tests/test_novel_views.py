@@ -336,3 +336,42 @@ def test_orbit_frames_against_the_oracle():
     # the ray-sharded schedule at world = 1 is the same image
     rgb_r, _ = render_novel_views(net, [cams[0]], trb, only_renderings=True, shard="rays")
     assert np.array_equal(rgb_r[0], rgb[0])
+
+
+@pytest.mark.gpu
+def test_orbit_of_120_frames_as_config4_is_written(tmp_path):
+    """BASELINE config 4 as written: the n_frames = 120 orbit of get_360cameras (src/utils.py:63-134) through render_novel_views, here at
+    64x64 with 16 + 16 samples so it stays a test.  120 frames come back; both schedules (frames dealt to ranks / rays of every frame dealt
+    to ranks, world = 1) give the same images; frames picked along the orbit equal rendering that camera alone; the per-frame tables are
+    built once (one encoder run for 120 target views)."""
+    from vanerf_amd.config import default_config
+    from vanerf_amd.model import VANeRF, get_360cameras
+    from vanerf_amd.novel_views import camera_to_cam_tar, render_novel_views
+    torch.manual_seed(0)
+    cfg = default_config()
+    cfg["models"]["VANeRF"]["dr_kwargs"].update(sample_per_ray_c=16, sample_per_ray_f=16)
+    net = VANeRF(cfg).cuda().eval()
+    net.load_state_dict(synth.make_full_weights(0), strict=False)
+    frame_cpu = synth.make_frame(seed=3, tar_h=64, tar_w=64)
+    frame = synth.to_device(frame_cpu, "cuda")
+    trb = synth.to_tr_batch(frame)
+    headpose = torch.eye(4)
+    headpose[:3, 3] = frame_cpu["targets"]["vert_world"][0].mean(0)
+    cams = get_360cameras(headpose[:3, :4].cuda(), 256.0, 1.0, 1.0, 64, 64, 0.71, 1.42, n_frames=120)
+    assert len(cams) == 120
+    runs = []
+    orig = net.geo_encoder.forward
+    net.geo_encoder.forward = lambda *a, **k: (runs.append(1), orig(*a, **k))[1]
+    rgb, src = render_novel_views(net, cams, trb, only_renderings=True)
+    assert rgb.shape == (120, 64, 64, 3) and src.shape == (1, 256, 256, 3) and len(runs) == 1
+    rgb_r, _ = render_novel_views(net, cams, trb, only_renderings=True, shard="rays")
+    assert np.array_equal(rgb_r, rgb)
+    for k in (0, 37, 119):
+        out = net.render_pifu_nerf(None, net, trb["im"], trb["cam"], trb["hand_type"], trb["targets"], camera_to_cam_tar(cams[k]), level=1,
+                                   sp_data=dict(trb["sp_data"]), fine=True, uniform=True, sample_per_ray_c=16, sample_per_ray_f=16,
+                                   src_foreground_mask=trb["src_foreground_mask"], bounds=trb["dr_data"]["bounds"], mask_at_box=None)
+        want = (out["tex_fg_fine"].clamp(0, 1).permute(1, 2, 0) * 255.0).to(torch.uint8).cpu().numpy()
+        assert np.array_equal(rgb[k], want), k
+    seen = rgb.reshape(120, -1).astype(np.int16)
+    assert (np.abs(seen[1:] - seen[:-1]).max(1) > 0).all()  # every step of the orbit moves the image
+    assert rgb.std() > 2  # hands and background in view

@@ -113,8 +113,10 @@ def render_novel_views(net, cameras, tr_batch, only_renderings=False, rank=0, wo
     by_rays = shard == "rays" and world > 1
     render_fn = render_fn or _default_render
     render_rows_fn = render_rows_fn or _default_render_rows
-    if hasattr(net, "attach_im_feat"):
-        net.attach_im_feat(tr_batch["im"])  # once per source frame (src/model.py:517)
+    if hasattr(net, "encoded"):
+        net.encoded(tr_batch["im"])  # once per source frame (src/model.py:517); the maps are kept for every target view of the orbit
+    elif hasattr(net, "attach_im_feat"):
+        net.attach_im_feat(tr_batch["im"])
     tr_batch["dr_data"]["tar"] = None
     mine = list(range(len(cameras))) if by_rays else frames_of_rank(len(cameras), rank, world)
     if (render_rows_fn is _default_render_rows if by_rays else render_fn is _default_render) and mine:  # the camera matrices go to the kernels by value: one read-back for the whole orbit, not one per frame
