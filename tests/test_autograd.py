@@ -155,3 +155,33 @@ def test_chunked_backward_gives_the_same_gradients():
     for k in grads[0]:
         # fp32 sums in another order (a wiring error gives O(1)); a bias in front of a normalisation layer has a zero gradient up to rounding noise
         assert (grads[0][k] - grads[1][k]).norm() <= 3e-3 * grads[0][k].norm() + 1e-4, k
+
+
+def test_geometry_branch_on_valid_samples_only_gives_the_same_gradients():
+    """torch_graph.networks_at evaluates GeoVisFusion / positional encoding / geometry MLP only where the pixel weight is non-zero (samples
+    inside the source view and foreground mask): the others pool to an exactly-zero latent and are masked by eval_func, so values and
+    gradients must equal the graph evaluated on every sample (blocky random foreground mask: about half of the samples drop out)."""
+    import numpy as np
+    from vanerf_amd import torch_graph as G
+    frame = synth.to_device(synth.make_frame(seed=3, tar_h=64, tar_w=64), "cuda")
+    blocks = (torch.rand(1, 1, 32, 32, generator=torch.Generator().manual_seed(5)) > 0.5).float()  # foreground in 8x8-pixel blocks
+    frame["src_foreground_mask"] = torch.nn.functional.interpolate(blocks, scale_factor=8, mode="nearest").view(1, 1, 1, 256, 256).to(frame["src_foreground_mask"]).contiguous()
+    grads, kept = [], []
+    orig = G.geometry_mlp
+    try:
+        G.geometry_mlp = lambda P, pe, fused, weight, **k: (kept.append(pe.shape[0]), orig(P, pe, fused, weight, **k))[1]
+        for compact in (False, True):
+            G.COMPACT_VALID = compact
+            net = _net(0.01)
+            torch.manual_seed(3)
+            np.random.seed(3)
+            out = _step(net, frame)
+            g = torch.Generator().manual_seed(1)
+            sum((out[k] * torch.randn(out[k].shape, generator=g).cuda()).sum() for k in KEYS).backward()
+            grads.append({k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None})
+    finally:
+        G.COMPACT_VALID, G.geometry_mlp = True, orig
+    assert kept[2] < kept[0] and kept[3] < kept[1], kept  # (coarse, fine) x (all samples, valid only)
+    assert set(grads[0]) == set(grads[1]) and len(grads[0]) > 100
+    for k in grads[0]:
+        assert (grads[0][k] - grads[1][k]).norm() <= 3e-3 * grads[0][k].norm() + 1e-4, k

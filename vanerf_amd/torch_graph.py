@@ -253,10 +253,24 @@ def networks_at(P, frame, pts, q_sdf, q_vis, knn, noise=None, sp_args=None):
     vert_xy = project_vertices(frame["verts"], cam)
     vis = frame["vert_vis"].float()
     qs, qv = q_sdf.view(-1, 1).float(), q_vis.view(-1, 1).float()
-    pix = [sample_map(f, xy) for f in frame["feat_geo"]]
-    fused = geo_fusion(P, frame["feat_geo"], pix, vert_xy, knn, vis, qv, qs)
-    pe = positional_encoding(pts, frame["kpt3d"], frame["extrin"], sp["sp_level"], sp["scale"], sp["sigma"])
-    geo, latent = geometry_mlp(P, pe, fused, weight)
+    # Samples outside the source view / foreground mask (about half of a pass) have pixel weight 0: their pooled latent is exactly zero
+    # (mean = 0 * x, var = 0 * ..), eval_func masks their sdf and rad, and no gradient flows back through the weight -- so GeoVisFusion, the
+    # positional encoding and the geometry MLP (85 % of the per-sample arithmetic) are evaluated on the valid samples only; same values,
+    # same gradients.  The texture branch below still runs on every sample: eval_func does not mask the colour.
+    keep = None
+    if COMPACT_VALID:
+        keep = mask.view(-1).nonzero().view(-1)
+        if keep.numel() == mask.shape[0]:
+            keep = None
+    sel = (lambda t: t) if keep is None else (lambda t: t.index_select(0, keep))
+    xy_k = sel(xy)
+    pix = [sample_map(f, xy_k) for f in frame["feat_geo"]]
+    fused = geo_fusion(P, frame["feat_geo"], pix, vert_xy, sel(knn), vis, sel(qv), sel(qs))
+    pe = positional_encoding(sel(pts), frame["kpt3d"], frame["extrin"], sp["sp_level"], sp["scale"], sp["sigma"])
+    geo, latent = geometry_mlp(P, pe, fused, sel(weight))
+    if keep is not None:
+        geo = torch.zeros(mask.shape[0], geo.shape[1], device=geo.device).index_copy(0, keep, geo)
+        latent = torch.zeros(mask.shape[0], latent.shape[1], device=latent.device).index_copy(0, keep, latent)
     latent24 = _Linear.apply(latent, P["ibr_compress_gfeat.weight"], P["ibr_compress_gfeat.bias"])
     table29 = frame.get("table29")
     if table29 is None:
@@ -291,6 +305,9 @@ def straight_through(value, graph):
 # whole patch 97 ms / 10.2 GiB, 2048 rays 115 ms / 5.4 GiB, 1024 rays 155 ms / 3.0 GiB, 512 rays 186 ms / 1.9 GiB.  With 288 GB of HBM the default is speed; model config key `grad_rays_per_chunk` sets it.
 # (bf16 operands for this graph's GEMMs were measured too: 106 ms, and the parameter gradients moved by 4e-2 relative -- dropped.)
 GRAD_RAYS_PER_CHUNK = None
+
+
+COMPACT_VALID = True  # networks_at: evaluate the geometry branch on valid samples only (tests compare both settings)
 
 
 class PassGradient(torch.autograd.Function):
