@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define VANERF_ABI_VERSION 7
+#define VANERF_ABI_VERSION 8
 
 #define VANERF_OK 0
 #define VANERF_EINVAL (-22)
@@ -142,9 +142,9 @@ int vanerf_vertex_visibility(const float* vert_xy01, const float* vert_z01, int 
 int vanerf_mesh_query(const float* verts, int nv, const int32_t* faces, int nf, const float* vert_vis,
                       const float* pts, int64_t n, float* sdf, uint8_t* vis, int32_t* face, void* stream);
 
-/* Acceleration structure for vanerf_mesh_query_accel (built per source frame on the device by the caller, see
- * vanerf_amd/renderer.py:MeshAccel).  Results are bit-identical to vanerf_mesh_query.                                   */
-/* Triangles / vertices per cluster the library was built with (the caller builds its tables with this value). */
+/* Acceleration structure for vanerf_mesh_query_accel, built per source frame by vanerf_mesh_accel_build below.
+ * Results are bit-identical to vanerf_mesh_query.                                                                        */
+/* Triangles / vertices per cluster the library was built with. */
 int vanerf_mesh_cluster_size(void);
 
 typedef struct {
@@ -157,8 +157,7 @@ typedef struct {
     int nfp, nc;
     const int32_t* cell_start; /* [G*G + 1] CSR offsets of the (y,z) grid used by the inside test */
     const int32_t* cell_tri;   /* original face ids per cell */
-    int G;
-    float y0, z0, cell_y, cell_z;
+    const float* grid;         /* [5] DEVICE record of that grid: y0, z0, cell size in y, in z, G as int bits.  cell = clamp(floor((c - c0) / size), 0, G-1) */
     const float* vsort;        /* [nvc*CL][4] Morton-sorted vertices (xyz, original index as int bits), padded with far points */
     const float* vbox;         /* [nvc][6]    AABB of each cluster of CL vertices */
     int nvc;
@@ -166,6 +165,17 @@ typedef struct {
                                 *           (then radius alone bounds the distance from the centre: a ball).  Every vertex of the cluster's triangles
                                 *           lies inside; second lower bound of the tile search of vanerf_mesh_query_accel (ray-grid hint) */
 } VanerfMeshAccel;
+
+/* Builds the tables above on the device, on `stream`, without a host synchronisation (six small launches; 0.1 ms for the two-hand MANO mesh):
+ *     verts[NV][3], faces[NF][3] int32 (indices inside [0, NV): the caller's responsibility) -> *out, whose pointers point into `tables`,
+ *     a caller-owned 16-byte-aligned device block of at least vanerf_mesh_accel_bytes(nv, nf, G, cell_capacity) bytes that must stay alive
+ *     (and unmodified) for as long as *out is used.  G x G = cells of the (y,z) grid of the inside test (1..256; 64 for a hand mesh);
+ *     cell_capacity >= nf = entries of the cells' triangle lists (64 * nf is ample: at G = 64 a triangle of a hand mesh touches ~20 cells).  Lists
+ *     that would not fit make the grid degrade, on the device, to ONE cell listing every triangle: slower inside test, same results.
+ *     Meshes of up to 16 384 faces / 4 096 vertices (the LDS-resident tables of vanerf_mesh_query_accel).                                  */
+int64_t vanerf_mesh_accel_bytes(int nv, int nf, int G, int cell_capacity);   /* < 0: error code */
+int vanerf_mesh_accel_build(const float* verts, int nv, const int32_t* faces, int nf, int G, int cell_capacity, void* tables,
+                            int64_t tables_bytes, VanerfMeshAccel* out, void* stream);
 
 /* knn_idx (may be NULL): 1-NN vertex of every point (knn_points K=1, src/networks.py:28), found in the same pass.
  * grid_nx, grid_ny, grid_s: optional layout hint (0,0,0 = none): pts are the samples of a grid_nx x grid_ny ray grid with grid_s

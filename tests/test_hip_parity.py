@@ -118,6 +118,89 @@ def test_mesh_query_accel_equals_brute_force(R):
         assert 0.02 < (s0 < 0).float().mean() < 0.9
 
 
+def test_mesh_accel_build_tables(R):
+    """vanerf_mesh_accel_build (device-side builder, no host synchronisation): the tables it writes are what the searches assume --
+    `orig` / the vertex table are permutations in Morton order, every triangle lies inside its sphere, its
+    cluster's box and cylinder, the (y,z) cell lists equal an exhaustive overlap test (ascending ids), and a cell capacity that is too
+    small degrades the grid to one cell with unchanged query results."""
+    frame = _frame(3, 64)
+    verts = dev(frame["targets"]["vert_world"][0].contiguous())
+    faces = dev(frame["targets"]["face_world"][0].to(torch.int32))
+    nv, nf, CL, G = verts.shape[0], faces.shape[0], R.MeshAccel.CL, 64
+    acc = R.MeshAccel(verts, faces, grid=G)
+    torch.cuda.synchronize()
+    nfp, nc, nvc = acc.c.nfp, acc.c.nc, acc.c.nvc
+    assert nfp == nc * CL >= nf and nvc * CL >= nv
+    f32, i32 = torch.float32, torch.int32
+    tri, orig = acc.table("tri", f32, (nfp, 3, 3)), acc.table("orig", i32, (nfp,))
+    sphere, tnorm = acc.table("sphere", f32, (nfp, 4)), acc.table("tnorm", f32, (nfp, 4))
+    cbox, cdisc = acc.table("cbox", f32, (nc, 6)), acc.table("cdisc", f32, (nc, 8))
+    vsort, vbox = acc.table("vsort", f32, (nvc * CL, 4)), acc.table("vbox", f32, (nvc, 6))
+    grid = acc.table("grid", f32, (5,))
+    assert torch.equal(orig[:nf].sort()[0], torch.arange(nf, device="cuda", dtype=i32)) and (orig[nf:] == 0x7FFFFFFF).all()
+    assert torch.equal(tri[:nf], verts[faces.long()][orig[:nf].long()]) and (tri[nf:] >= 1.0e4).all()
+    # Morton order of the centroids (same quantisation as the kernel: ties keep the original order)
+    lo, hi = verts.min(0)[0], verts.max(0)[0]
+
+    def part(x):
+        x = (x | (x << 16)) & 0x030000FF
+        x = (x | (x << 8)) & 0x0300F00F
+        x = (x | (x << 4)) & 0x030C30C3
+        return (x | (x << 2)) & 0x09249249
+
+    def morton(c):
+        q = ((c - lo) / (hi - lo + 1e-9) * 1023.0).clamp(0, 1023).long()
+        return part(q[:, 0]) | (part(q[:, 1]) << 1) | (part(q[:, 2]) << 2)
+
+    tv = verts[faces.long()]
+    cen = ((tv[:, 0] + tv[:, 1]) + tv[:, 2]) / 3.0
+    in_order = lambda keys: (keys[1:] >= keys[:-1]).float().mean().item()  # (a centroid on a bin edge may quantise differently in torch)
+    assert in_order(morton(cen)[orig[:nf].long()]) > 0.99
+    vid = vsort[:, 3].contiguous().view(i32)
+    assert torch.equal(vid[:nv].sort()[0], torch.arange(nv, device="cuda", dtype=i32)) and (vid[nv:] == 0x7FFFFFFF).all()
+    assert in_order(morton(verts)[vid[:nv].long()]) > 0.99
+    assert torch.equal(vsort[:nv, :3], verts[vid[:nv].long()])
+    # bounds hold
+    assert ((tri - sphere[:, None, :3]).norm(dim=-1) <= sphere[:, None, 3]).all()
+    assert (((tri - sphere[:, None, :3]) * tnorm[:, None, :3]).sum(-1).abs() <= 1e-6).all()  # corners in the plane through the centroid
+    cl = tri.view(nc, CL * 3, 3)
+    assert (cl >= cbox[:, None, :3]).all() and (cl <= cbox[:, None, 3:]).all()
+    off = cl - cdisc[:, None, :3]
+    h = (off * cdisc[:, None, 4:7]).sum(-1)
+    assert (h.abs() <= cdisc[:, None, 7]).all() and ((off.pow(2).sum(-1) - h * h).clamp_min(0).sqrt() <= cdisc[:, None, 3]).all()
+    vc = vsort[:, :3].view(nvc, CL, 3)
+    assert (vc >= vbox[:, None, :3]).all() and (vc <= vbox[:, None, 3:]).all()
+    # the (y,z) grid
+    assert grid[4:5].view(i32).item() == G and torch.equal(grid[:2], lo[1:]) and torch.equal(grid[2:4], (hi[1:] - lo[1:]) / G)
+    cell = lambda c, a: torch.floor((c - grid[a]) / grid[2 + a]).long().clamp(0, G - 1)
+    ylo, yhi = cell(tv[..., 1].min(1)[0], 0), cell(tv[..., 1].max(1)[0], 0)
+    zlo, zhi = cell(tv[..., 2].min(1)[0], 1), cell(tv[..., 2].max(1)[0], 1)
+    ar = torch.arange(G, device="cuda")
+    in_y = (ar[:, None] >= ylo[None]) & (ar[:, None] <= yhi[None])
+    in_z = (ar[:, None] >= zlo[None]) & (ar[:, None] <= zhi[None])
+    overlap = (in_y[:, None, :] & in_z[None, :, :]).reshape(G * G, nf)
+    start = acc.table("cell_start", i32, (G * G + 1,))
+    assert torch.equal(start.long(), torch.cat([torch.zeros(1, dtype=torch.long, device="cuda"), overlap.sum(1).cumsum(0)]))
+    total = int(start[-1])
+    assert 4 * nf < total <= 64 * nf
+    assert torch.equal(acc.table("cell_tri", i32, (total,)).long(), overlap.nonzero()[:, 1])
+    # too small a capacity: one cell holding every triangle, same answers
+    p = dev(_points_near_mesh(frame, 20000, seed=1))
+    vv = dev((torch.rand(nv, generator=torch.Generator().manual_seed(0)) > 0.5).float())
+    small = R.MeshAccel(verts, faces, grid=G, cell_capacity=nf)
+    a = R.mesh_query_accel(acc, verts, faces, vv, p, want_face=True)
+    b = R.mesh_query_accel(small, verts, faces, vv, p, want_face=True)
+    assert small.table("grid", f32, (5,))[4:5].view(i32).item() == 1
+    assert torch.equal(small.table("cell_start", i32, (2,)), torch.tensor([0, nf], dtype=i32, device="cuda"))
+    assert all(torch.equal(x, y) for x, y in zip(a, b))
+    ref = R.mesh_query(verts, faces, vv, p, want_face=True)
+    assert all(torch.equal(x, y) for x, y in zip(a[:3], ref))
+    with pytest.raises(Exception):
+        R.MeshAccel(verts, faces, grid=G, cell_capacity=nf - 1)
+    with pytest.raises(Exception):
+        R.MeshAccel(verts, faces, grid=300)
+
+
 @pytest.mark.parametrize("seed,hw,tar_w,orbit,S,step", [(11, 512, 334, 15.0, 24, 2), (5, 256, 256, 70.0, 32, 2), (3, 64, 64, 8.0, 16, 1)])
 def test_mesh_query_tile_search_equals_brute_force(R, seed, hw, tar_w, orbit, S, step):
     """The tile searches of vanerf_mesh_query_accel (ray-grid hint: a wave = one depth of an 8x8 pixel tile, candidates found for the tile's

@@ -12,7 +12,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int64, c_uint
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VANERF_HIP_LIB") or os.path.join(_HERE, "lib", "libvanerf_hip.so")  # the override is for A/B runs of kernel builds (tools/)
-ABI_VERSION = 7
+ABI_VERSION = 8
 NUM_LAYERS = 20
 
 if not os.path.exists(LIB_PATH):
@@ -48,7 +48,7 @@ class VanerfFrame(Structure):
 class VanerfMeshAccel(Structure):
     _fields_ = [
         ("tri", _FP), ("sphere", _FP), ("tnorm", _FP), ("orig", _FP), ("cbox", _FP), ("nfp", c_int), ("nc", c_int),
-        ("cell_start", _FP), ("cell_tri", _FP), ("G", c_int), ("y0", c_float), ("z0", c_float), ("cell_y", c_float), ("cell_z", c_float),
+        ("cell_start", _FP), ("cell_tri", _FP), ("grid", _FP),
         ("vsort", _FP), ("vbox", _FP), ("nvc", c_int), ("cdisc", _FP),
     ]
 
@@ -71,6 +71,8 @@ _SIGS = {
     "vanerf_abi_version": (c_int, []),
     "vanerf_last_error": (c_char_p, []),
     "vanerf_mesh_cluster_size": (c_int, []),
+    "vanerf_mesh_accel_bytes": (c_int64, [c_int, c_int, c_int, c_int]),
+    "vanerf_mesh_accel_build": (c_int, [_FP, c_int, _FP, c_int, c_int, c_int, c_void_p, c_int64, POINTER(VanerfMeshAccel), c_void_p]),
     "vanerf_weights_pack": (c_int, [POINTER(VanerfWeightTable), c_int, POINTER(c_void_p)]),
     "vanerf_weights_free": (c_int, [c_void_p]),
     "vanerf_weights_short_groups": (c_int, [c_void_p, POINTER(c_uint64)]),

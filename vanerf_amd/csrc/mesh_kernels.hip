@@ -149,34 +149,68 @@ __global__ __launch_bounds__(MQ_BLOCK) void mesh_query_kernel(const float* __res
     vis[i] = sv >= 0.1f;
 }
 
-// get_visibility: one thread per raster pixel, faces streamed through LDS
+// get_visibility: one thread per raster pixel, one block per 16 x 16 pixel tile.  Faces are streamed through LDS 256 at a time; a face is
+// staged only if it can cover a pixel centre of the tile (front facing, not degenerate, bounding box within 1e-3 units of the tile -- the
+// inside test of a pixel further than that from the box of an ordinary face fails in fp32 whatever the rounding; faces with a vertex behind
+// the camera plane and needles are staged for every tile).  The staged faces keep their order (the first of equal depths wins, as in the full scan),
+// and the per-pixel arithmetic is unchanged, so the result is the full scan's, bit for bit (13 x fewer tests on the two-hand mesh).
 constexpr int RV_BLOCK = 256;
-constexpr int RV_TILE = 256;
+constexpr int RV_T = 16;
 
 __global__ __launch_bounds__(RV_BLOCK) void raster_kernel(const float* __restrict__ xy01, const float* __restrict__ z01,
                                                           const int32_t* __restrict__ F, int nf, int S, int32_t* __restrict__ pix_to_face)
 {
-    __shared__ float s_v[RV_TILE][9];
-    const int pix = blockIdx.x * RV_BLOCK + threadIdx.x;
-    const bool live = pix < S * S;
-    const int px = pix % S, py = pix / S;
+    __shared__ float s_v[RV_BLOCK][9];
+    __shared__ int s_id[RV_BLOCK];
+    __shared__ int s_wcnt[RV_BLOCK / 64];
+    const int tiles_x = (S + RV_T - 1) / RV_T;
+    const int px0 = (blockIdx.x % tiles_x) * RV_T, py0 = (blockIdx.x / tiles_x) * RV_T;
+    const int px = px0 + (threadIdx.x & (RV_T - 1)), py = py0 + threadIdx.x / RV_T;
+    const bool live = px < S && py < S;
     const float cx = -1.0f + (2.0f * (float)px + 1.0f) / (float)S;
     const float cy = -1.0f + (2.0f * (float)py + 1.0f) / (float)S;
+    const float tol = 1e-3f;
+    const float tx_lo = -1.0f + (2.0f * (float)px0 + 1.0f) / (float)S - tol, tx_hi = -1.0f + (2.0f * (float)min(px0 + RV_T - 1, S - 1) + 1.0f) / (float)S + tol;
+    const float ty_lo = -1.0f + (2.0f * (float)py0 + 1.0f) / (float)S - tol, ty_hi = -1.0f + (2.0f * (float)min(py0 + RV_T - 1, S - 1) + 1.0f) / (float)S + tol;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float bestz = INFINITY;
     int bf = -1;
-    for (int f0 = 0; f0 < nf; f0 += RV_TILE) {
-        const int m = min(RV_TILE, nf - f0);
+    for (int f0 = 0; f0 < nf; f0 += RV_BLOCK) {
+        const int f = f0 + threadIdx.x;
+        float v[9];
+        bool keep = false;
+        if (f < nf) {
+            for (int c = 0; c < 3; ++c) {
+                const int vi = F[3 * f + c];
+                v[3 * c + 0] = (xy01[2 * vi] + 1.0f) / 2.0f;
+                v[3 * c + 1] = (xy01[2 * vi + 1] + 1.0f) / 2.0f;
+                v[3 * c + 2] = (z01[vi] + 1.0f) / 2.0f;
+            }
+            const float area = (v[6] - v[0]) * (v[4] - v[1]) - (v[7] - v[1]) * (v[3] - v[0]);
+            const float xlo = fminf(v[0], fminf(v[3], v[6])), xhi = fmaxf(v[0], fmaxf(v[3], v[6]));
+            const float ylo = fminf(v[1], fminf(v[4], v[7])), yhi = fmaxf(v[1], fmaxf(v[4], v[7]));
+            // the box test only speaks for an ordinary face: all three depths positive (then the signs of the perspective-corrected weights are
+            // the signs of the edge functions) and not a needle (area against its box: the edge functions of a needle cancel to rounding noise)
+            const bool ordinary = v[2] > 0.0f && v[5] > 0.0f && v[8] > 0.0f && area > 1e-4f * ((xhi - xlo) * (yhi - ylo));
+            const bool off_tile = xlo > tx_hi || xhi < tx_lo || ylo > ty_hi || yhi < ty_lo;
+            keep = !(area < 0.0f) && !(fabsf(area) <= 1e-8f) && !(ordinary && off_tile); // (the first two: the early-outs of the loop below)
+        }
+        const unsigned long long m = __ballot(keep);
+        __syncthreads(); // the previous pass's readers are done
+        if (lane == 0) s_wcnt[wave] = __popcll(m);
         __syncthreads();
-        for (int k = threadIdx.x; k < m * 3; k += RV_BLOCK) {
-            const int f = k / 3, c = k % 3;
-            const int vi = F[3 * (f0 + f) + c];
-            s_v[f][3 * c + 0] = (xy01[2 * vi] + 1.0f) / 2.0f;
-            s_v[f][3 * c + 1] = (xy01[2 * vi + 1] + 1.0f) / 2.0f;
-            s_v[f][3 * c + 2] = (z01[vi] + 1.0f) / 2.0f;
+        int at = __popcll(m & ((1ull << lane) - 1ull)), cnt = 0;
+        for (int w = 0; w < RV_BLOCK / 64; ++w) {
+            if (w < wave) at += s_wcnt[w];
+            cnt += s_wcnt[w];
+        }
+        if (keep) {
+            for (int k = 0; k < 9; ++k) s_v[at][k] = v[k];
+            s_id[at] = f;
         }
         __syncthreads();
-        for (int f = 0; f < m; ++f) {
-            const float* v0 = &s_v[f][0]; const float* v1 = &s_v[f][3]; const float* v2 = &s_v[f][6];
+        for (int k = 0; k < cnt; ++k) {
+            const float* v0 = &s_v[k][0]; const float* v1 = &s_v[k][3]; const float* v2 = &s_v[k][6];
             const float area = (v2[0] - v0[0]) * (v1[1] - v0[1]) - (v2[1] - v0[1]) * (v1[0] - v0[0]);
             if (area < 0.0f) continue;
             if (fabsf(area) <= 1e-8f) continue;
@@ -190,10 +224,10 @@ __global__ __launch_bounds__(RV_BLOCK) void raster_kernel(const float* __restric
             const float pz = (b0 * v0[2] + b1 * v1[2]) + b2 * v2[2];
             if (pz < 0.0f) continue;
             if (!(b0 > 0.0f && b1 > 0.0f && b2 > 0.0f)) continue;
-            if (pz < bestz) { bestz = pz; bf = f0 + f; }
+            if (pz < bestz) { bestz = pz; bf = s_id[k]; }
         }
     }
-    if (live) pix_to_face[pix] = bf;
+    if (live) pix_to_face[py * S + px] = bf;
 }
 
 __global__ void mark_visible_kernel(const int32_t* __restrict__ pix_to_face, int npix, const int32_t* __restrict__ F, int nf,
@@ -235,7 +269,7 @@ __global__ __launch_bounds__(256) void knn1_kernel(const float4* __restrict__ ve
 //     ties resolve to the lowest ORIGINAL face index, as the brute-force scan does;
 //   * inside test: a G x G grid over the mesh's (y,z) extent lists the triangles whose (y,z) bounding box touches each
 //     cell; the +x ray of a point can only cross triangles of its own cell.
-// The structure is built per source frame by vanerf_amd/renderer.py:MeshAccel (torch on the device).
+// The structure is built per source frame by vanerf_mesh_accel_build (end of this file).
 #ifndef VANERF_MA_CL
 #define VANERF_MA_CL 4
 #endif
@@ -288,6 +322,9 @@ __global__ __launch_bounds__(MA_BLOCK) void mesh_query_accel_kernel(const Vanerf
     for (int k = threadIdx.x; k < A.nc * 6; k += MA_BLOCK) s_box[k] = A.cbox[k];
     for (int k = threadIdx.x; k < A.nvc * 6; k += MA_BLOCK) s_vbox[k] = A.vbox[k];
     for (int k = threadIdx.x; k < A.nvc * CL; k += MA_BLOCK) s_vs[k] = reinterpret_cast<const float4*>(A.vsort)[k];
+    // (y,z) grid of the inside test: written on the device by vanerf_mesh_accel_build (uniform loads)
+    const float grid_y0 = A.grid[0], grid_z0 = A.grid[1], grid_cy = A.grid[2], grid_cz = A.grid[3];
+    const int grid_G = __float_as_int(A.grid[4]);
     __syncthreads();
     // Work mapping.  The pruning below is data dependent, so a wave runs the UNION of its lanes' candidate lists.  With the
     // ray-grid hint (gnx x gny rays, gS samples per ray, sample index = ray * gS + depth) a wave takes one depth of an 8 x 8
@@ -708,10 +745,10 @@ __global__ __launch_bounds__(MA_BLOCK) void mesh_query_accel_kernel(const Vanerf
         // inside test on the (y,z) grid
         int cnt = 0;
         {
-            int cy = (int)floorf((p.y - A.y0) / A.cell_y), cz = (int)floorf((p.z - A.z0) / A.cell_z);
-            cy = min(max(cy, 0), A.G - 1);
-            cz = min(max(cz, 0), A.G - 1);
-            const int cell = cy * A.G + cz;
+            int cy = (int)floorf((p.y - grid_y0) / grid_cy), cz = (int)floorf((p.z - grid_z0) / grid_cz);
+            cy = min(max(cy, 0), grid_G - 1);
+            cz = min(max(cz, 0), grid_G - 1);
+            const int cell = cy * grid_G + cz;
             const int e = A.cell_start[cell + 1];
             for (int k = A.cell_start[cell]; k < e; ++k) {
                 const int f = A.cell_tri[k];
@@ -770,7 +807,8 @@ extern "C" int vanerf_vertex_visibility(const float* vert_xy01, const float* ver
         hipStream_t st = (hipStream_t)stream;
         const int npix = raster * raster;
         HIP_CHECK(hipMemsetAsync(vert_vis, 0, sizeof(float) * nv, st));
-        hipLaunchKernelGGL(raster_kernel, dim3((npix + RV_BLOCK - 1) / RV_BLOCK), dim3(RV_BLOCK), 0, st, vert_xy01, vert_z01, faces, nf, raster, pix_to_face);
+        const int tiles = (raster + RV_T - 1) / RV_T;
+        hipLaunchKernelGGL(raster_kernel, dim3((unsigned)(tiles * tiles)), dim3(RV_BLOCK), 0, st, vert_xy01, vert_z01, faces, nf, raster, pix_to_face);
         hipLaunchKernelGGL(mark_visible_kernel, dim3((npix + 255) / 256), dim3(256), 0, st, pix_to_face, npix, faces, nf, vert_vis);
         HIP_CHECK(hipGetLastError());
     });
@@ -811,9 +849,8 @@ extern "C" int vanerf_mesh_query_accel(const VanerfMeshAccel* accel, const float
         if (n == 0) return; // an empty batch is valid (and has null data pointers)
         if (!accel || !verts || !faces || !vert_vis || !pts || !sdf || !vis) throw_error("vanerf_mesh_query_accel: null argument");
         const VanerfMeshAccel& A = *accel;
-        if (!A.tri || !A.sphere || !A.tnorm || !A.orig || !A.cbox || !A.cdisc || !A.cell_start || !A.cell_tri) throw_error("vanerf_mesh_query_accel: accel has a null pointer");
+        if (!A.tri || !A.sphere || !A.tnorm || !A.orig || !A.cbox || !A.cdisc || !A.cell_start || !A.cell_tri || !A.grid) throw_error("vanerf_mesh_query_accel: accel has a null pointer");
         if (A.nc <= 0 || A.nc > MA_MAX_CLUSTERS || A.nfp != A.nc * CL || A.nfp < nf) throw_error("vanerf_mesh_query_accel: bad cluster table (nc=%d nfp=%d nf=%d)", A.nc, A.nfp, nf);
-        if (A.G <= 0 || !(A.cell_y > 0.0f) || !(A.cell_z > 0.0f)) throw_error("vanerf_mesh_query_accel: bad grid");
         if (nv <= 0 || nf <= 0 || n < 0) throw_error("vanerf_mesh_query_accel: nv=%d nf=%d n=%lld", nv, nf, (long long)n);
         if (!A.vsort || !A.vbox || A.nvc <= 0 || A.nvc > MA_MAX_VCLUSTERS || A.nvc * CL < nv)
             throw_error("vanerf_mesh_query_accel: bad vertex cluster table (nvc=%d nv=%d)", A.nvc, nv);
@@ -843,3 +880,401 @@ extern "C" int vanerf_debug_mesh_phases(unsigned long long* out8, int reset)
 #endif
 
 extern "C" int vanerf_mesh_cluster_size(void) { return CL; }
+
+// ---------------------------------------------------------------------------------------------------------------
+// vanerf_mesh_accel_build: the tables of VanerfMeshAccel, built on the device without a host synchronisation (one per source frame).
+// Six small launches on the caller's stream:
+//   bounds_sort   (2 blocks) vertex bounds -> grid record; Morton keys of triangle centroids (block 0) and of vertices (block 1), bitonic sort in LDS
+//   tables        per triangle cluster: sorted corners, bounding spheres / discs, cluster AABB and cylinder; per vertex cluster: vsort, vbox
+//   cell_count    per triangle: +1 in every (y,z) cell its bounding box touches
+//   cell_scan     (1 block)  CSR offsets; if the lists would not fit `cell_capacity` the grid degrades to ONE cell holding every triangle
+//                 (the inside test then scans all of them: slower, same answer)
+//   cell_fill     per triangle: its id into the cells' lists (atomic cursors)
+//   cell_order    one wave per cell: ascending ids (a deterministic table whatever the order of the atomics)
+// Every bound carries the slack of the fp32 arithmetic that produced it (1e-5 relative + 1e-6 of the largest coordinate), as the pruning
+// tests of mesh_query_accel_kernel assume.
+namespace {
+
+constexpr int AB_THREADS = 1024;
+
+__device__ __forceinline__ unsigned part1by2(unsigned x)
+{
+    x = (x | (x << 16)) & 0x030000FFu;
+    x = (x | (x << 8)) & 0x0300F00Fu;
+    x = (x | (x << 4)) & 0x030C30C3u;
+    return (x | (x << 2)) & 0x09249249u;
+}
+
+__device__ __forceinline__ unsigned morton30(f3 c, f3 lo, f3 hi)
+{
+    auto q = [](float v, float l, float h) { return (unsigned)fminf(fmaxf((v - l) / (h - l + 1e-9f) * 1023.0f, 0.0f), 1023.0f); };
+    return part1by2(q(c.x, lo.x, hi.x)) | (part1by2(q(c.y, lo.y, hi.y)) << 1) | (part1by2(q(c.z, lo.z, hi.z)) << 2);
+}
+
+__device__ __forceinline__ f3 vert3(const float* V, int i) { return {V[3 * i], V[3 * i + 1], V[3 * i + 2]}; }
+
+__device__ void bitonic_sort_lds(unsigned long long* s, int n)
+{
+    for (int k = 2; k <= n; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < n; i += AB_THREADS) {
+                const int o = i ^ j;
+                if (o > i) {
+                    const unsigned long long a = s[i], b = s[o];
+                    if ((a > b) == ((i & k) == 0)) { s[i] = b; s[o] = a; }
+                }
+            }
+            __syncthreads();
+        }
+}
+
+__global__ __launch_bounds__(AB_THREADS) void accel_bounds_sort_kernel(const float* __restrict__ V, int nv, const int32_t* __restrict__ F, int nf, int G,
+                                                                       int nt2, int nv2, float* __restrict__ grid, int32_t* __restrict__ tri_order,
+                                                                       int32_t* __restrict__ vert_order, int32_t* __restrict__ counts)
+{
+    extern __shared__ unsigned long long s_keys[];
+    __shared__ float s_red[6][AB_THREADS / 64];
+    __shared__ float s_b[6];
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int i = threadIdx.x; i < nv; i += AB_THREADS)
+        for (int a = 0; a < 3; ++a) {
+            const float v = V[3 * i + a];
+            lo[a] = fminf(lo[a], v);
+            hi[a] = fmaxf(hi[a], v);
+        }
+    for (int a = 0; a < 3; ++a)
+        for (int o = 32; o > 0; o >>= 1) {
+            lo[a] = fminf(lo[a], __shfl_xor(lo[a], o));
+            hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], o));
+        }
+    if ((threadIdx.x & 63) == 0)
+        for (int a = 0; a < 3; ++a) {
+            s_red[a][threadIdx.x >> 6] = lo[a];
+            s_red[3 + a][threadIdx.x >> 6] = hi[a];
+        }
+    if (blockIdx.x == 0)
+        for (int k = threadIdx.x; k < G * G; k += AB_THREADS) counts[k] = 0;
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        float r = s_red[threadIdx.x][0];
+        for (int w = 1; w < AB_THREADS / 64; ++w) r = threadIdx.x < 3 ? fminf(r, s_red[threadIdx.x][w]) : fmaxf(r, s_red[threadIdx.x][w]);
+        s_b[threadIdx.x] = r;
+    }
+    __syncthreads();
+    const f3 blo = {s_b[0], s_b[1], s_b[2]}, bhi = {s_b[3], s_b[4], s_b[5]};
+    if (blockIdx.x == 1) { // the second block orders the vertices while the first orders the triangles (both know the bounds)
+        for (int i = threadIdx.x; i < nv2; i += AB_THREADS)
+            s_keys[i] = i < nv ? ((unsigned long long)morton30(vert3(V, i), blo, bhi) << 32) | (unsigned)i : ~0ull;
+        __syncthreads();
+        bitonic_sort_lds(s_keys, nv2);
+        for (int i = threadIdx.x; i < nv; i += AB_THREADS) vert_order[i] = (int32_t)(s_keys[i] & 0xffffffffu);
+        return;
+    }
+    if (threadIdx.x == 0) {
+        // cell = clamp(floor((c - c0) / size), 0, G - 1): the SAME fp32 expression in cell_range() below and in the query kernel, so the monotone
+        // map sends every point of a triangle's (y,z) bounding box into the triangle's cell range
+        const float cy = (bhi.y - blo.y) / (float)G, cz = (bhi.z - blo.z) / (float)G;
+        grid[0] = blo.y;
+        grid[1] = blo.z;
+        grid[2] = cy > 0.0f ? cy : 1e-6f;
+        grid[3] = cz > 0.0f ? cz : 1e-6f;
+        grid[4] = __int_as_float(G);
+    }
+    for (int i = threadIdx.x; i < nt2; i += AB_THREADS) {
+        unsigned long long key = ~0ull;
+        if (i < nf) {
+            const f3 a = vert3(V, F[3 * i]), b = vert3(V, F[3 * i + 1]), c = vert3(V, F[3 * i + 2]);
+            const f3 cen = {((a.x + b.x) + c.x) / 3.0f, ((a.y + b.y) + c.y) / 3.0f, ((a.z + b.z) + c.z) / 3.0f};
+            key = ((unsigned long long)morton30(cen, blo, bhi) << 32) | (unsigned)i;
+        }
+        s_keys[i] = key;
+    }
+    __syncthreads();
+    bitonic_sort_lds(s_keys, nt2);
+    for (int i = threadIdx.x; i < nf; i += AB_THREADS) tri_order[i] = (int32_t)(s_keys[i] & 0xffffffffu);
+}
+
+__global__ __launch_bounds__(256) void accel_tables_kernel(const float* __restrict__ V, int nv, const int32_t* __restrict__ F, int nf, int nc, int nvc,
+                                                           const int32_t* __restrict__ tri_order, const int32_t* __restrict__ vert_order,
+                                                           float* __restrict__ tri, float* __restrict__ sphere, float* __restrict__ tnorm,
+                                                           int32_t* __restrict__ orig, float* __restrict__ cbox, float* __restrict__ cdisc,
+                                                           float* __restrict__ vsort, float* __restrict__ vbox)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t < nc) {
+        f3 P[CL * 3], nsum = {0.0f, 0.0f, 0.0f};
+        float pad = 0.0f;
+        for (int k = 0; k < CL; ++k) {
+            const int slot = t * CL + k;
+            int f = 0x7FFFFFFF;
+            f3 a, b, c;
+            if (slot < nf) {
+                f = tri_order[slot];
+                a = vert3(V, F[3 * f]);
+                b = vert3(V, F[3 * f + 1]);
+                c = vert3(V, F[3 * f + 2]);
+            } else { // far-away (degenerate) triangles that can never be the closest
+                a = {1.0e4f, 1.0e4f, 1.0e4f};
+                b = {1.0e4f + 1.0f, 1.0e4f + 1.0f, 1.0e4f + 1.0f};
+                c = {1.0e4f + 2.0f, 1.0e4f + 2.0f, 1.0e4f + 2.0f};
+            }
+            P[3 * k] = a, P[3 * k + 1] = b, P[3 * k + 2] = c;
+            const f3 cr[3] = {a, b, c};
+            float amax = 0.0f;
+            for (int j = 0; j < 3; ++j) {
+                tri[9 * slot + 3 * j] = cr[j].x, tri[9 * slot + 3 * j + 1] = cr[j].y, tri[9 * slot + 3 * j + 2] = cr[j].z;
+                amax = fmaxf(amax, fmaxf(fabsf(cr[j].x), fmaxf(fabsf(cr[j].y), fabsf(cr[j].z))));
+            }
+            orig[slot] = f;
+            const f3 cen = {((a.x + b.x) + c.x) / 3.0f, ((a.y + b.y) + c.y) / 3.0f, ((a.z + b.z) + c.z) / 3.0f};
+            const float a_t = amax * 1e-6f + 1e-9f; // absolute slack of the oriented bounds (fp32 error of centres and normals)
+            float r2 = 0.0f;
+            for (int j = 0; j < 3; ++j) {
+                const f3 d = sub3(cr[j], cen);
+                r2 = fmaxf(r2, dot3(d, d));
+            }
+            const float rad = sqrtf(r2) * (1.0f + 1e-5f) + a_t;
+            sphere[4 * slot] = cen.x, sphere[4 * slot + 1] = cen.y, sphere[4 * slot + 2] = cen.z, sphere[4 * slot + 3] = rad;
+            // oriented bound: the triangle lies in the plane through its centroid, within `rad` of it
+            const f3 e1 = sub3(b, a), e2 = sub3(c, a);
+            const f3 nrm = {e1.y * e2.z - e1.z * e2.y, e1.z * e2.x - e1.x * e2.z, e1.x * e2.y - e1.y * e2.x};
+            const float nlen = sqrtf(dot3(nrm, nrm));
+            const float inv = nlen > 1e-20f ? 1.0f / fmaxf(nlen, 1e-30f) : 0.0f;
+            tnorm[4 * slot] = nrm.x * inv, tnorm[4 * slot + 1] = nrm.y * inv, tnorm[4 * slot + 2] = nrm.z * inv, tnorm[4 * slot + 3] = 1e5f * a_t * a_t;
+            nsum = {nsum.x + nrm.x, nsum.y + nrm.y, nsum.z + nrm.z};
+            pad = fmaxf(pad, a_t);
+        }
+        f3 lo = P[0], hi = P[0], cc = {0.0f, 0.0f, 0.0f};
+        for (int j = 0; j < CL * 3; ++j) {
+            lo = {fminf(lo.x, P[j].x), fminf(lo.y, P[j].y), fminf(lo.z, P[j].z)};
+            hi = {fmaxf(hi.x, P[j].x), fmaxf(hi.y, P[j].y), fmaxf(hi.z, P[j].z)};
+            cc = {cc.x + P[j].x, cc.y + P[j].y, cc.z + P[j].z};
+        }
+        cbox[6 * t] = lo.x, cbox[6 * t + 1] = lo.y, cbox[6 * t + 2] = lo.z, cbox[6 * t + 3] = hi.x, cbox[6 * t + 4] = hi.y, cbox[6 * t + 5] = hi.z;
+        // cylinder around the cluster (tile search): centre = mean corner, axis = normalised sum of the triangles' area normals, radius /
+        // half height = the largest lateral / axial offset of a corner
+        cc = {cc.x / (float)(CL * 3), cc.y / (float)(CL * 3), cc.z / (float)(CL * 3)};
+        const float cal = sqrtf(dot3(nsum, nsum));
+        const float cinv = cal > 1e-20f ? 1.0f / fmaxf(cal, 1e-30f) : 0.0f;
+        const f3 ax = {nsum.x * cinv, nsum.y * cinv, nsum.z * cinv};
+        float lat = 0.0f, hh = 0.0f;
+        for (int j = 0; j < CL * 3; ++j) {
+            const f3 off = sub3(P[j], cc);
+            const float h = dot3(off, ax);
+            lat = fmaxf(lat, sqrtf(fmaxf(dot3(off, off) - h * h, 0.0f)));
+            hh = fmaxf(hh, fabsf(h));
+        }
+        float* cd = cdisc + 8 * t;
+        cd[0] = cc.x, cd[1] = cc.y, cd[2] = cc.z, cd[3] = lat * (1.0f + 1e-5f) + pad;
+        cd[4] = ax.x, cd[5] = ax.y, cd[6] = ax.z, cd[7] = hh * (1.0f + 1e-5f) + pad;
+    } else if (t - nc < nvc) {
+        const int c = t - nc;
+        f3 lo = {INFINITY, INFINITY, INFINITY}, hi = {-INFINITY, -INFINITY, -INFINITY};
+        for (int k = 0; k < CL; ++k) {
+            const int slot = c * CL + k;
+            int idx = 0x7FFFFFFF;
+            f3 v = {1.0e4f, 1.0e4f, 1.0e4f};
+            if (slot < nv) {
+                idx = vert_order[slot];
+                v = vert3(V, idx);
+            }
+            vsort[4 * slot] = v.x, vsort[4 * slot + 1] = v.y, vsort[4 * slot + 2] = v.z, vsort[4 * slot + 3] = __int_as_float(idx);
+            lo = {fminf(lo.x, v.x), fminf(lo.y, v.y), fminf(lo.z, v.z)};
+            hi = {fmaxf(hi.x, v.x), fmaxf(hi.y, v.y), fmaxf(hi.z, v.z)};
+        }
+        vbox[6 * c] = lo.x, vbox[6 * c + 1] = lo.y, vbox[6 * c + 2] = lo.z, vbox[6 * c + 3] = hi.x, vbox[6 * c + 4] = hi.y, vbox[6 * c + 5] = hi.z;
+    }
+}
+
+// cells of the (y,z) grid the bounding box of triangle f touches: [ylo, yhi] x [zlo, zhi]
+__device__ __forceinline__ void cell_range(const float* V, const int32_t* F, int f, const float* grid, int G, int& ylo, int& yhi, int& zlo, int& zhi)
+{
+    const f3 a = vert3(V, F[3 * f]), b = vert3(V, F[3 * f + 1]), c = vert3(V, F[3 * f + 2]);
+    const float y0 = grid[0], z0 = grid[1], sy = grid[2], sz = grid[3];
+    auto cell = [G](float v, float c0, float size) { return min(max((int)floorf((v - c0) / size), 0), G - 1); };
+    ylo = cell(fminf(a.y, fminf(b.y, c.y)), y0, sy);
+    yhi = cell(fmaxf(a.y, fmaxf(b.y, c.y)), y0, sy);
+    zlo = cell(fminf(a.z, fminf(b.z, c.z)), z0, sz);
+    zhi = cell(fmaxf(a.z, fmaxf(b.z, c.z)), z0, sz);
+}
+
+__global__ __launch_bounds__(256) void accel_cell_count_kernel(const float* __restrict__ V, const int32_t* __restrict__ F, int nf, int G,
+                                                               const float* __restrict__ grid, int32_t* __restrict__ counts)
+{
+    const int f = blockIdx.x * 256 + threadIdx.x;
+    if (f >= nf) return;
+    int ylo, yhi, zlo, zhi;
+    cell_range(V, F, f, grid, G, ylo, yhi, zlo, zhi);
+    for (int y = ylo; y <= yhi; ++y)
+        for (int z = zlo; z <= zhi; ++z) atomicAdd(&counts[y * G + z], 1);
+}
+
+__global__ __launch_bounds__(AB_THREADS) void accel_cell_scan_kernel(int G, int nf, int capacity, float* __restrict__ grid, int32_t* __restrict__ counts,
+                                                                     int32_t* __restrict__ cell_start)
+{
+    __shared__ int s_part[AB_THREADS];
+    const int n = G * G, per = (n + AB_THREADS - 1) / AB_THREADS, b0 = threadIdx.x * per, b1 = min(n, b0 + per);
+    int sum = 0;
+    for (int k = b0; k < b1; ++k) sum += counts[k];
+    s_part[threadIdx.x] = sum;
+    __syncthreads();
+    for (int o = 1; o < AB_THREADS; o <<= 1) { // inclusive scan of the partial sums
+        const int v = (int)threadIdx.x >= o ? s_part[threadIdx.x - o] : 0;
+        __syncthreads();
+        s_part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    const int total = s_part[AB_THREADS - 1];
+    if (total > capacity) { // the lists do not fit: one cell with every triangle
+        if (threadIdx.x == 0) {
+            grid[4] = __int_as_float(1);
+            cell_start[0] = 0;
+            cell_start[1] = nf;
+        }
+        return;
+    }
+    int run = s_part[threadIdx.x] - sum;
+    for (int k = b0; k < b1; ++k) {
+        cell_start[k] = run;
+        run += counts[k];
+        counts[k] = 0; // the fill's cursors
+    }
+    if (threadIdx.x == 0) cell_start[n] = total;
+}
+
+__global__ __launch_bounds__(256) void accel_cell_fill_kernel(const float* __restrict__ V, const int32_t* __restrict__ F, int nf, int G,
+                                                              const float* __restrict__ grid, int32_t* __restrict__ cursors,
+                                                              const int32_t* __restrict__ cell_start, int32_t* __restrict__ unordered,
+                                                              int32_t* __restrict__ cell_tri)
+{
+    const int f = blockIdx.x * 256 + threadIdx.x;
+    if (f >= nf) return;
+    if (__float_as_int(grid[4]) != G) { // degraded to one cell (accel_cell_scan_kernel)
+        cell_tri[f] = f;
+        return;
+    }
+    int ylo, yhi, zlo, zhi;
+    cell_range(V, F, f, grid, G, ylo, yhi, zlo, zhi);
+    for (int y = ylo; y <= yhi; ++y)
+        for (int z = zlo; z <= zhi; ++z) {
+            const int cell = y * G + z;
+            unordered[cell_start[cell] + atomicAdd(&cursors[cell], 1)] = f;
+        }
+}
+
+__global__ __launch_bounds__(256) void accel_cell_order_kernel(int G, const float* __restrict__ grid, const int32_t* __restrict__ cell_start,
+                                                               const int32_t* __restrict__ unordered, int32_t* __restrict__ cell_tri)
+{
+    // one wave per cell: an id's place in the ascending list is the number of smaller ids (ids are unique within a cell)
+    const int cell = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (cell >= G * G || __float_as_int(grid[4]) != G) return;
+    const int b = cell_start[cell], e = cell_start[cell + 1];
+    for (int i = b + lane; i < e; i += 64) {
+        const int v = unordered[i];
+        int rank = 0;
+        for (int j = b; j < e; ++j) rank += unordered[j] < v;
+        cell_tri[b + rank] = v;
+    }
+}
+
+struct AccelLayout {
+    size_t tri, sphere, tnorm, orig, cbox, cdisc, cell_start, cell_tri, grid, vsort, vbox, tri_order, vert_order, counts, unordered, total;
+    int nfp, nc, nvp, nvc;
+};
+
+AccelLayout accel_layout(int nv, int nf, int G, int capacity)
+{
+    AccelLayout L{};
+    L.nc = (nf + CL - 1) / CL, L.nfp = L.nc * CL, L.nvc = (nv + CL - 1) / CL, L.nvp = L.nvc * CL;
+    size_t at = 0;
+    auto take = [&at](size_t bytes) { const size_t o = at; at += (bytes + 255) & ~(size_t)255; return o; };
+    L.tri = take(sizeof(float) * 9 * L.nfp);
+    L.sphere = take(sizeof(float) * 4 * L.nfp);
+    L.tnorm = take(sizeof(float) * 4 * L.nfp);
+    L.orig = take(sizeof(int32_t) * L.nfp);
+    L.cbox = take(sizeof(float) * 6 * L.nc);
+    L.cdisc = take(sizeof(float) * 8 * L.nc);
+    L.cell_start = take(sizeof(int32_t) * ((size_t)G * G + 1));
+    L.cell_tri = take(sizeof(int32_t) * (size_t)capacity);
+    L.grid = take(sizeof(float) * 8);
+    L.vsort = take(sizeof(float) * 4 * L.nvp);
+    L.vbox = take(sizeof(float) * 6 * L.nvc);
+    L.tri_order = take(sizeof(int32_t) * nf);
+    L.vert_order = take(sizeof(int32_t) * nv);
+    L.counts = take(sizeof(int32_t) * (size_t)G * G);
+    L.unordered = take(sizeof(int32_t) * (size_t)capacity);
+    L.total = at;
+    return L;
+}
+
+void accel_check_sizes(int nv, int nf, int G, int capacity)
+{
+    if (nv <= 0 || nf <= 0) throw_error("vanerf_mesh_accel_build: nv=%d nf=%d", nv, nf);
+    if ((nf + CL - 1) / CL > MA_MAX_CLUSTERS || (nv + CL - 1) / CL > MA_MAX_VCLUSTERS)
+        throw_error("vanerf_mesh_accel_build: mesh too large (at most %d faces, %d vertices)", MA_MAX_CLUSTERS * CL, MA_MAX_VCLUSTERS * CL);
+    if (G < 1 || G > 256) throw_error("vanerf_mesh_accel_build: grid size %d outside [1, 256]", G);
+    if (capacity < nf) throw_error("vanerf_mesh_accel_build: cell_capacity %d is below the number of faces %d", capacity, nf);
+}
+
+int pow2_at_least(int n)
+{
+    int p = 1;
+    while (p < n) p <<= 1;
+    return p;
+}
+
+} // namespace
+
+extern "C" int64_t vanerf_mesh_accel_bytes(int nv, int nf, int G, int cell_capacity)
+{
+    int64_t bytes = -1;
+    const int rc = guarded([&] {
+        accel_check_sizes(nv, nf, G, cell_capacity);
+        bytes = (int64_t)accel_layout(nv, nf, G, cell_capacity).total;
+    });
+    return rc == VANERF_OK ? bytes : (int64_t)rc;
+}
+
+extern "C" int vanerf_mesh_accel_build(const float* verts, int nv, const int32_t* faces, int nf, int G, int cell_capacity, void* tables,
+                                       int64_t tables_bytes, VanerfMeshAccel* out, void* stream)
+{
+    return guarded([&] {
+        if (!verts || !faces || !tables || !out) throw_error("vanerf_mesh_accel_build: null argument");
+        accel_check_sizes(nv, nf, G, cell_capacity);
+        const AccelLayout L = accel_layout(nv, nf, G, cell_capacity);
+        if (tables_bytes < (int64_t)L.total) throw_error("vanerf_mesh_accel_build: table block of %lld bytes, %zu needed", (long long)tables_bytes, L.total);
+        if (reinterpret_cast<uintptr_t>(tables) % 16 != 0) throw_error("vanerf_mesh_accel_build: table block must be 16-byte aligned");
+        char* base = static_cast<char*>(tables);
+        auto F32 = [base](size_t o) { return reinterpret_cast<float*>(base + o); };
+        auto I32 = [base](size_t o) { return reinterpret_cast<int32_t*>(base + o); };
+        const hipStream_t st = (hipStream_t)stream;
+        const int nt2 = pow2_at_least(nf), nv2 = pow2_at_least(nv);
+        const size_t lds = sizeof(unsigned long long) * (size_t)(nt2 > nv2 ? nt2 : nv2);
+        if (lds > 64 * 1024)
+            HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(accel_bounds_sort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(accel_bounds_sort_kernel, dim3(2), dim3(AB_THREADS), lds, st, verts, nv, faces, nf, G, nt2, nv2, F32(L.grid), I32(L.tri_order),
+                           I32(L.vert_order), I32(L.counts));
+        HIP_CHECK(hipGetLastError());
+        hipLaunchKernelGGL(accel_tables_kernel, dim3((unsigned)((L.nc + L.nvc + 255) / 256)), dim3(256), 0, st, verts, nv, faces, nf, L.nc, L.nvc,
+                           I32(L.tri_order), I32(L.vert_order), F32(L.tri), F32(L.sphere), F32(L.tnorm), I32(L.orig), F32(L.cbox), F32(L.cdisc),
+                           F32(L.vsort), F32(L.vbox));
+        HIP_CHECK(hipGetLastError());
+        const unsigned fb = (unsigned)((nf + 255) / 256);
+        hipLaunchKernelGGL(accel_cell_count_kernel, dim3(fb), dim3(256), 0, st, verts, faces, nf, G, F32(L.grid), I32(L.counts));
+        HIP_CHECK(hipGetLastError());
+        hipLaunchKernelGGL(accel_cell_scan_kernel, dim3(1), dim3(AB_THREADS), 0, st, G, nf, cell_capacity, F32(L.grid), I32(L.counts), I32(L.cell_start));
+        HIP_CHECK(hipGetLastError());
+        hipLaunchKernelGGL(accel_cell_fill_kernel, dim3(fb), dim3(256), 0, st, verts, faces, nf, G, F32(L.grid), I32(L.counts), I32(L.cell_start),
+                           I32(L.unordered), I32(L.cell_tri));
+        HIP_CHECK(hipGetLastError());
+        hipLaunchKernelGGL(accel_cell_order_kernel, dim3((unsigned)((G * G + 3) / 4)), dim3(256), 0, st, G, F32(L.grid), I32(L.cell_start),
+                           I32(L.unordered), I32(L.cell_tri));
+        HIP_CHECK(hipGetLastError());
+        VanerfMeshAccel A{};
+        A.tri = F32(L.tri), A.sphere = F32(L.sphere), A.tnorm = F32(L.tnorm), A.orig = I32(L.orig), A.cbox = F32(L.cbox), A.cdisc = F32(L.cdisc);
+        A.nfp = L.nfp, A.nc = L.nc;
+        A.cell_start = I32(L.cell_start), A.cell_tri = I32(L.cell_tri), A.grid = F32(L.grid);
+        A.vsort = F32(L.vsort), A.vbox = F32(L.vbox), A.nvc = L.nvc;
+        *out = A;
+    });
+}
