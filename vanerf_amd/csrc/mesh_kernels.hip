@@ -306,11 +306,14 @@ __device__ __forceinline__ float box_dist2(f3 p, const float* b)
     return (dx * dx + dy * dy) + dz * dz;
 }
 
+__device__ unsigned long long g_ma_queue[64]; // work-queue heads of mesh_query_accel_kernel, one per launch in flight (vanerf_mesh_query_accel)
+
 __global__ __launch_bounds__(MA_BLOCK) void mesh_query_accel_kernel(const VanerfMeshAccel A, const float* __restrict__ V,
                                                                     const int32_t* __restrict__ F, const float* __restrict__ vert_vis,
                                                                     const float* __restrict__ P, long long n, float* __restrict__ sdf,
                                                                     uint8_t* __restrict__ vis, int32_t* __restrict__ face,
-                                                                    int32_t* __restrict__ knn, int gnx, int gny, int gS)
+                                                                    int32_t* __restrict__ knn, int gnx, int gny, int gS,
+                                                                    unsigned long long* __restrict__ queue)
 {
     // dynamic LDS: [nvc*16] sorted vertices (float4) | [nvc][6] vertex-cluster boxes | [nc][6] triangle-cluster boxes
     extern __shared__ float4 s_dyn[];
@@ -331,13 +334,20 @@ __global__ __launch_bounds__(MA_BLOCK) void mesh_query_accel_kernel(const Vanerf
     // pixel tile: 64 points a few millimetres apart that prune almost identically.  Without the hint (gnx == 0) consecutive
     // lanes take consecutive samples (one whole ray per wave: its points span the bounding box, ~4x more work per wave).
     const int lane = threadIdx.x & 63;
-    const long long wave0 = ((long long)blockIdx.x * MA_BLOCK + threadIdx.x) >> 6, nwaves = ((long long)gridDim.x * MA_BLOCK) >> 6;
+    // Work queue: a wave claims its next 64 points with one atomic.  The cost of a wave's search varies 10x with the tile's distance from
+    // the mesh; a fixed assignment left 40 % of the wave slots idle behind the slowest waves (2.45 of 4 waves per SIMD on average).
+    auto claim = [&]() {
+        unsigned long long v = 0ull;
+        if (lane == 0) v = atomicAdd(queue, 1ull);
+        return (long long)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) |
+                           (unsigned)__builtin_amdgcn_readfirstlane((int)v));
+    };
     const int ntx = (gnx + 7) >> 3, nty = (gny + 7) >> 3;
     const long long nwork = gnx > 0 ? (long long)ntx * nty * gS : (n + 63) >> 6;
 #ifdef VANERF_MESH_PHASES
     unsigned long long ph[16] = {}, tprev = __builtin_amdgcn_s_memtime();
 #endif
-    for (long long w = wave0; w < nwork; w += nwaves) {
+    for (long long w = claim(); w < nwork; w = claim()) {
         // every lane keeps a point (the searches below are wave-cooperative): a lane beyond the grid border / the end of the batch
         // repeats a neighbour's point and does not store
         long long i;
@@ -614,6 +624,84 @@ __global__ __launch_bounds__(MA_BLOCK) void mesh_query_accel_kernel(const Vanerf
                 ns += __builtin_popcountll(m);
             }
             __builtin_amdgcn_wave_barrier();
+            float thr_eval = thr;
+            if (ns > TL_LIST) {
+                // A tile decimetres from the mesh: hundreds of clusters lie within 2 rho of the seed's distance.  Two stages instead.
+                // 1. the exact minimum D at tc: only clusters within the seed's distance U itself can hold it (a short list);
+                // 2. the clusters that can hold a triangle passing (ii): every closest point of cluster c lies in the ball (m_c, R_c) around
+                //    its cylinder, so  |u_t - u_D| <= |u_m - u_D| + 1.05 R_c / |tc - m_c|  (R_c < |tc - m_c| / 2; chord <= angle <= 1.05 sine),
+                //    and d(tc, t) >= the cluster's lower bound: c matters only if  bound_c - D  passes may_win with that difference.
+                auto cyl = [&](int cl_, float& lb2, float& du) { // lower bound (squared) of cluster cl_ at tc; du needs uD (stage 2)
+                    const float4 cd = reinterpret_cast<const float4*>(A.cdisc)[2 * cl_], cn = reinterpret_cast<const float4*>(A.cdisc)[2 * cl_ + 1];
+                    const f3 e = {tc.x - cd.x, tc.y - cd.y, tc.z - cd.z};
+                    const float L2 = dot3(e, e), h = (cn.x * e.x + cn.y * e.y) + cn.z * e.z;
+                    const float dh = fmaxf(fabsf(h) * (1.0f - 1e-5f) - cn.w, 0.0f), dl = fmaxf(sqrtf(fmaxf(L2 - h * h, 0.0f)) * (1.0f - 1e-5f) - cd.w, 0.0f);
+                    lb2 = fmaxf(box_dist2(tc, s_box + 6 * cl_), (dh * dh + dl * dl) * (1.0f - 1e-5f));
+                    du = sqrtf(cd.w * cd.w + cn.w * cn.w) * (1.0f + 1e-5f) / fmaxf(sqrtf(L2), 1e-20f); // R_c / |tc - m_c|
+                    return e;
+                };
+                auto list_clusters = [&](auto keep_fn) {
+                    int n_ = 0;
+                    for (int c0 = 0; c0 < A.nc; c0 += 64) {
+                        const int cl_ = min(c0 + lane, A.nc - 1);
+                        const bool keep = c0 + lane < A.nc && keep_fn(cl_);
+                        const unsigned long long m = __ballot(keep);
+                        const int pos = n_ + mbcnt(m);
+                        if (keep && pos < TL_LIST) my_list[pos] = (unsigned short)cl_;
+                        n_ += __builtin_popcountll(m);
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    return n_;
+                };
+                const float thr1 = U * (1.0f + 1e-4f) + 1e-12f;
+                __builtin_amdgcn_wave_barrier(); // (the first collect's writers are done with the list)
+                const int n1 = list_clusters([&](int cl_) { float lb2, du; cyl(cl_, lb2, du); return lb2 <= thr1; });
+                float b1 = INFINITY;
+                int t1 = cseed * CL;
+                if (lane < CL) { const Tri T = load_tri(cseed * CL + lane); b1 = point_tri_dist2(tc, T.a, T.b, T.c); t1 = cseed * CL + lane; }
+                if (n1 <= TL_LIST) {
+                    for (int j = lane; j < n1 * CL; j += 64) {
+                        const int t = (int)my_list[j / CL] * CL + j % CL;
+                        const float4 sp = reinterpret_cast<const float4*>(A.sphere)[t], tn = reinterpret_cast<const float4*>(A.tnorm)[t];
+                        if (disc_lb2(sp, tn, tc) <= thr1) {
+                            const Tri T = load_tri(t);
+                            const float d = point_tri_dist2(tc, T.a, T.b, T.c);
+                            if (d < b1) { b1 = d; t1 = t; }
+                        }
+                    }
+                } else { // (a flat part of the mesh faces the tile: hundreds of clusters are as near as the seed) every triangle, 64 at a time
+                    float bw = thr1;
+                    for (int t0 = 0; t0 < A.nfp; t0 += 64) {
+                        const int t = min(t0 + lane, A.nfp - 1);
+                        const float4 sp = reinterpret_cast<const float4*>(A.sphere)[t], tn = reinterpret_cast<const float4*>(A.tnorm)[t];
+                        if (disc_lb2(sp, tn, tc) <= bw) {
+                            const Tri T = load_tri(t);
+                            const float d = point_tri_dist2(tc, T.a, T.b, T.c);
+                            if (d < b1) { b1 = d; t1 = t; }
+                        }
+                        bw = fminf(bw, wave_min(b1) * (1.0f + 1e-4f) + 1e-12f);
+                    }
+                }
+                const float D2a = wave_min(b1), Da = sqrtf(D2a);
+                const unsigned long long mD = __ballot(b1 == D2a);
+                if (!mD || !(Da > 1e-4f)) return false; // (a NaN tile; a tile this close to the mesh does not overflow the list)
+                f3 qa;
+                { const Tri T = load_tri(__builtin_amdgcn_readlane(t1, __builtin_ctzll(mD))); point_tri_dist2_q(tc, T.a, T.b, T.c, qa); }
+                const f3 ua = {(tc.x - qa.x) / Da, (tc.y - qa.y) / Da, (tc.z - qa.z) / Da};
+                __builtin_amdgcn_wave_barrier(); // (stage 1's readers are done with the list)
+                ns = list_clusters([&](int cl_) {
+                    float lb2, x;
+                    const f3 e = cyl(cl_, lb2, x);
+                    float du = 2.0f; // |u - u'| <= 2 always
+                    if (x < 0.5f) {
+                        const float inv = 1.0f / fmaxf(sqrtf(dot3(e, e)), 1e-20f);
+                        const float ex = e.x * inv - ua.x, ey = e.y * inv - ua.y, ez = e.z * inv - ua.z;
+                        du = sqrtf((ex * ex + ey * ey) + ez * ez) + 1.05f * x + 1e-5f;
+                    }
+                    return may_win(sqrtf(lb2), Da, du, true);
+                });
+                thr_eval = sq_plus(D2a);
+            }
 #ifdef VANERF_MESH_PHASES
             if (lane == 0 && ns > TL_LIST) ph[14] += 1; // list overflow
 #endif
@@ -634,7 +722,7 @@ __global__ __launch_bounds__(MA_BLOCK) void mesh_query_accel_kernel(const Vanerf
                     const int t = (int)my_list[j / CL] * CL + j % CL;
                     t_it[it] = t;
                     const float4 sp = reinterpret_cast<const float4*>(A.sphere)[t], tn = reinterpret_cast<const float4*>(A.tnorm)[t];
-                    d_it[it] = disc_lb2(sp, tn, tc) <= thr ? 0.0f : INFINITY; // 0 = "evaluate me"
+                    d_it[it] = disc_lb2(sp, tn, tc) <= thr_eval ? 0.0f : INFINITY; // 0 = "evaluate me"
                 }
             }
 #pragma unroll
@@ -659,6 +747,7 @@ __global__ __launch_bounds__(MA_BLOCK) void mesh_query_accel_kernel(const Vanerf
             // candidate table, from where every lane evaluates them for its own point
             float* const ctab = s_cand[threadIdx.x >> 6][0];
             int K = 0;
+            unsigned cbits = 0u; // bit `it`: this lane's triangle of round `it` is a candidate
 #pragma unroll
             for (int it = 0; it < TL_IT; ++it) {
                 if (it * 64 < nt && __ballot(d_it[it] <= Tf)) {
@@ -673,6 +762,7 @@ __global__ __launch_bounds__(MA_BLOCK) void mesh_query_accel_kernel(const Vanerf
                         cand = may_win(d, D, sqrtf((ex * ex + ey * ey) + ez * ez), have);
                     }
                     const unsigned long long m = __ballot(cand);
+                    cbits |= cand ? 1u << it : 0u;
                     const int pos = K + mbcnt(m);
                     if (cand && pos < TL_CAND) {
                         float* e = ctab + pos * 12;
@@ -683,20 +773,41 @@ __global__ __launch_bounds__(MA_BLOCK) void mesh_query_accel_kernel(const Vanerf
                 }
             }
 #ifdef VANERF_MESH_PHASES
-            if (lane == 0 && K > TL_CAND) ph[15] += 1; // candidate table overflow
-#endif
-            if (K > TL_CAND) return false;
-            __builtin_amdgcn_wave_barrier();
-#ifdef VANERF_MESH_PHASES
+            if (lane == 0 && K > TL_CAND) ph[15] += 1; // more candidates than the table holds: evaluated in batches
             if (lane == 0) ph[11] += K; // per-lane evaluations of the tile search
 #endif
-            for (int k = 0; k < K; ++k) {
-                const float4 e0 = reinterpret_cast<const float4*>(ctab + k * 12)[0], e1 = reinterpret_cast<const float4*>(ctab + k * 12)[1],
-                             e2 = reinterpret_cast<const float4*>(ctab + k * 12)[2];
-                const f3 a = {e0.x, e0.y, e0.z}, b = {e0.w, e1.x, e1.y}, c3 = {e1.z, e1.w, e2.x};
-                const float d = point_tri_dist2(p, a, b, c3);
-                const int of = __float_as_int(e2.y);
-                if (d < best || (d == best && of < bf)) { best = d; bf = of; }
+            // every lane evaluates the candidates for its own point, a table-full at a time (a tile facing a flat part of the mesh from
+            // decimetres away has ~60: any triangle under the tile's footprint can be the closest of one of its points)
+            for (int base = 0; base < K; base += TL_CAND) {
+                if (base > 0) {
+                    __builtin_amdgcn_wave_barrier(); // the previous batch's readers are done
+                    int k0 = 0;
+#pragma unroll
+                    for (int it = 0; it < TL_IT; ++it) {
+                        const unsigned long long m = __ballot((cbits >> it) & 1u);
+                        if (m) {
+                            const int pos = k0 + mbcnt(m) - base;
+                            if (((m >> lane) & 1ull) && pos >= 0 && pos < TL_CAND) {
+                                const int j = it * 64 + lane, t = (int)my_list[j / CL] * CL + j % CL; // (as in the rounds above: the list is still there)
+                                const Tri T = load_tri(t);
+                                float* e = ctab + pos * 12;
+                                e[0] = T.a.x; e[1] = T.a.y; e[2] = T.a.z; e[3] = T.b.x; e[4] = T.b.y; e[5] = T.b.z; e[6] = T.c.x; e[7] = T.c.y; e[8] = T.c.z;
+                                e[9] = __int_as_float(A.orig[t]);
+                            }
+                            k0 += __builtin_popcountll(m);
+                        }
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                const int kn = min(TL_CAND, K - base);
+                for (int k = 0; k < kn; ++k) {
+                    const float4 e0 = reinterpret_cast<const float4*>(ctab + k * 12)[0], e1 = reinterpret_cast<const float4*>(ctab + k * 12)[1],
+                                 e2 = reinterpret_cast<const float4*>(ctab + k * 12)[2];
+                    const f3 a = {e0.x, e0.y, e0.z}, b = {e0.w, e1.x, e1.y}, c3 = {e1.z, e1.w, e2.x};
+                    const float d = point_tri_dist2(p, a, b, c3);
+                    const int of = __float_as_int(e2.y);
+                    if (d < best || (d == best && of < bf)) { best = d; bf = of; }
+                }
             }
             return true;
         };
@@ -861,10 +972,26 @@ extern "C" int vanerf_mesh_query_accel(const VanerfMeshAccel* accel, const float
         if (n == 0) return;
         if (grid_nx != 0 && (grid_nx < 0 || grid_ny <= 0 || grid_s <= 0 || (long long)grid_nx * grid_ny * grid_s != n))
             throw_error("vanerf_mesh_query_accel: ray-grid hint %d x %d x %d does not match n = %lld", grid_nx, grid_ny, grid_s, (long long)n);
+        // as many blocks as the chip holds at once (the work queue hands out the points); one of 64 queue slots per launch, zeroed on the stream
+        static unsigned long long* const queue_base = [] {
+            void* ptr = nullptr;
+            HIP_CHECK(hipGetSymbolAddress(&ptr, HIP_SYMBOL(g_ma_queue)));
+            return static_cast<unsigned long long*>(ptr);
+        }();
+        static const int resident = [&] {
+            int dev = 0, cus = 256, per_cu = 2;
+            HIP_CHECK(hipGetDevice(&dev));
+            HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+            HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mesh_query_accel_kernel, MA_BLOCK, lds));
+            return cus * (per_cu > 0 ? per_cu : 1);
+        }();
+        static std::atomic<unsigned> next_slot{0};
+        unsigned long long* const queue = queue_base + (next_slot.fetch_add(1u) % 64u);
+        HIP_CHECK(hipMemsetAsync(queue, 0, sizeof(unsigned long long), (hipStream_t)stream));
         long long blocks = (n + MA_BLOCK - 1) / MA_BLOCK;
-        if (blocks > 256 * 8) blocks = 256 * 8;
+        if (blocks > resident) blocks = resident;
         hipLaunchKernelGGL(mesh_query_accel_kernel, dim3((unsigned)blocks), dim3(MA_BLOCK), lds, (hipStream_t)stream, A, verts, faces, vert_vis,
-                           pts, (long long)n, sdf, vis, face, knn_idx, grid_nx, grid_ny, grid_s);
+                           pts, (long long)n, sdf, vis, face, knn_idx, grid_nx, grid_ny, grid_s, queue);
         HIP_CHECK(hipGetLastError());
     });
 }
