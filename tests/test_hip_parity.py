@@ -201,7 +201,8 @@ def test_mesh_accel_build_tables(R):
         R.MeshAccel(verts, faces, grid=300)
 
 
-@pytest.mark.parametrize("seed,hw,tar_w,orbit,S,step", [(11, 512, 334, 15.0, 24, 2), (5, 256, 256, 70.0, 32, 2), (3, 64, 64, 8.0, 16, 1)])
+@pytest.mark.parametrize("seed,hw,tar_w,orbit,S,step", [(11, 512, 334, 15.0, 24, 2), (5, 256, 256, 70.0, 32, 2), (3, 64, 64, 8.0, 16, 1),
+                                                        (7, 96, 80, 40.0, 15, 1)])  # (an odd number of depths: the last depth group of a tile is half empty)
 def test_mesh_query_tile_search_equals_brute_force(R, seed, hw, tar_w, orbit, S, step):
     """The tile searches of vanerf_mesh_query_accel (ray-grid hint: a wave = one depth of an 8x8 pixel tile, candidates found for the tile's
     centre by the whole wave, then evaluated per lane) on the samples of real ray grids -- fine tiles of the benchmark camera, a large view

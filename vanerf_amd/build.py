@@ -24,6 +24,12 @@ def _stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+# The one exception, in bytes per lane: mesh_query_accel_kernel at two depths per tile search and four waves per SIMD parks a few
+# loop-invariant address registers in scratch (stored once per wave, re-read once per 128 points).  Measured against the alternatives on
+# the benchmark view: 2.14 ms with these spills, 2.27 ms without them at three waves per SIMD, 2.61 ms at one depth per search.
+SCRATCH_ALLOWED = {"mesh_query_accel_kernel": 64}
+
+
 def _check_no_scratch(src, remarks):
     """Every kernel of this library is written to live in registers: a build whose register allocation spills to scratch memory is a
     performance cliff that still passes every test (query_kernel once went from 0 to 59 spilled VGPRs through an innocent-looking
@@ -34,7 +40,7 @@ def _check_no_scratch(src, remarks):
         if m:
             name = m.group(1)
         m = re.search(r"ScratchSize \[bytes/lane\]: (\d+)", line)
-        if m and int(m.group(1)) > 0:
+        if m and int(m.group(1)) > max((v for k, v in SCRATCH_ALLOWED.items() if k in (name or "")), default=0):
             bad.append((name, int(m.group(1))))
     if bad and os.environ.get("VANERF_ALLOW_SCRATCH") != "1":
         raise RuntimeError(f"{src}: kernels spill to scratch memory: {bad} (set VANERF_ALLOW_SCRATCH=1 to build anyway)")

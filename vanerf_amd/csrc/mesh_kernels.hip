@@ -276,7 +276,7 @@ __global__ __launch_bounds__(256) void knn1_kernel(const float4* __restrict__ ve
 constexpr int CL = VANERF_MA_CL; // triangles (and vertices) per cluster.  Measured on the benchmark view: 16 -> 6.35 ms, 8 -> 4.80, 4 -> 4.37
                                  // (box tests are cheap since they are done per wave first; small clusters mean fewer per-triangle tests)
 #ifndef VANERF_MA_BLOCK
-#define VANERF_MA_BLOCK 512
+#define VANERF_MA_BLOCK 1024 // one block per CU: 16 waves share the LDS copy of the vertex / box tables (53 KB for the two-hand mesh)
 #endif
 constexpr int MA_BLOCK = VANERF_MA_BLOCK;
 constexpr int MA_MAX_CLUSTERS = 4096;
@@ -287,8 +287,12 @@ constexpr int MA_MAX_VCLUSTERS = 1024;
 #endif
 constexpr int TL_LIST = VANERF_TL_LIST;
 constexpr int TL_IT = TL_LIST * CL / 64;
+#ifndef VANERF_MA_ND
+#define VANERF_MA_ND 2
+#endif
+constexpr int ND = VANERF_MA_ND; // consecutive depths of a pixel tile a wave takes at once: one tile search, ND per-lane evaluations
 constexpr int TL_CAND = 40; // triangles (9 floats + original index, padded to 12) a wave's candidate table holds
-static_assert(TL_LIST * CL % 64 == 0 && MA_MAX_CLUSTERS <= 65536, "candidate lists hold 16-bit cluster ids in whole rounds of 64");
+static_assert(TL_LIST * CL % 64 == 0 && 64 % CL == 0 && MA_MAX_CLUSTERS <= 65536, "candidate lists hold 16-bit cluster ids in whole rounds of 64");
 
 // Diagnostic build only (-DVANERF_MESH_PHASES): s_memtime deltas per phase, summed over waves (tools/perf_mesh.py --phases)
 #ifdef VANERF_MESH_PHASES
@@ -298,6 +302,28 @@ __device__ unsigned long long g_ma_phase[16];
 #define MPH(k) do { } while (0)
 #endif
 
+// Wave-wide reductions on the DPP path (quad swaps, half-row / row mirrors, row broadcasts; the result is read from lane 63 into a scalar
+// register): six VALU moves instead of the six LDS round trips of __shfl_xor's ds_bpermute, and no address registers.  The searches below
+// reduce a few dozen times per 64 points and are bound by exactly this kind of dependent latency.
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xF, false); } // masked-off rows keep v
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ float dpp_f(float v) { return __int_as_float(dpp_i<CTRL, ROW_MASK>(__float_as_int(v))); }
+#define VANERF_WAVE_REDUCE(T, DPP, OP)                                                                                                   \
+    v = OP(v, DPP<0xB1>(v));        /* quad_perm [1,0,3,2] */                                                                             \
+    v = OP(v, DPP<0x4E>(v));        /* quad_perm [2,3,0,1] */                                                                             \
+    v = OP(v, DPP<0x141>(v));       /* row_half_mirror */                                                                                 \
+    v = OP(v, DPP<0x140>(v));       /* row_mirror: every lane holds its row of 16 */                                                      \
+    v = OP(v, DPP<0x142, 0xA>(v));  /* row_bcast15 into rows 1, 3 */                                                                      \
+    v = OP(v, DPP<0x143, 0xC>(v));  /* row_bcast31 into rows 2, 3: lane 63 holds all 64 */
+__device__ __forceinline__ float wave_min_f(float v) { VANERF_WAVE_REDUCE(float, dpp_f, fminf) return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63)); }
+__device__ __forceinline__ float wave_max_f(float v) { VANERF_WAVE_REDUCE(float, dpp_f, fmaxf) return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63)); }
+__device__ __forceinline__ int wave_min_i(int v) { VANERF_WAVE_REDUCE(int, dpp_i, min) return __builtin_amdgcn_readlane(v, 63); }
+#undef VANERF_WAVE_REDUCE
+
+// a value that is the same in every lane, moved to a scalar register (the tile's box, centre, radius: they live through the whole search)
+__device__ __forceinline__ float uni(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+
 __device__ __forceinline__ float box_dist2(f3 p, const float* b)
 {
     const float dx = fmaxf(fmaxf(b[0] - p.x, p.x - b[3]), 0.0f);
@@ -306,9 +332,12 @@ __device__ __forceinline__ float box_dist2(f3 p, const float* b)
     return (dx * dx + dy * dy) + dz * dz;
 }
 
+#ifndef VANERF_MA_ATTR
+#define VANERF_MA_ATTR
+#endif
 __device__ unsigned long long g_ma_queue[64]; // work-queue heads of mesh_query_accel_kernel, one per launch in flight (vanerf_mesh_query_accel)
 
-__global__ __launch_bounds__(MA_BLOCK) void mesh_query_accel_kernel(const VanerfMeshAccel A, const float* __restrict__ V,
+__global__ __launch_bounds__(MA_BLOCK) VANERF_MA_ATTR void mesh_query_accel_kernel(const VanerfMeshAccel A, const float* __restrict__ V,
                                                                     const int32_t* __restrict__ F, const float* __restrict__ vert_vis,
                                                                     const float* __restrict__ P, long long n, float* __restrict__ sdf,
                                                                     uint8_t* __restrict__ vis, int32_t* __restrict__ face,
@@ -319,6 +348,7 @@ __global__ __launch_bounds__(MA_BLOCK) void mesh_query_accel_kernel(const Vanerf
     extern __shared__ float4 s_dyn[];
     __shared__ unsigned short s_list[MA_BLOCK / 64][TL_LIST]; // per-wave candidate lists of the tile searches
     __shared__ __attribute__((aligned(16))) float s_cand[MA_BLOCK / 64][TL_CAND][12];
+    __shared__ float s_dit[MA_BLOCK / 64][TL_IT][64]; // per-wave, per-lane distances of the searches' rounds (registers are the scarce resource here)
     float4* s_vs = s_dyn;
     float* s_vbox = reinterpret_cast<float*>(s_vs + A.nvc * CL);
     float* s_box = s_vbox + A.nvc * 6;
@@ -343,28 +373,44 @@ __global__ __launch_bounds__(MA_BLOCK) void mesh_query_accel_kernel(const Vanerf
                            (unsigned)__builtin_amdgcn_readfirstlane((int)v));
     };
     const int ntx = (gnx + 7) >> 3, nty = (gny + 7) >> 3;
-    const long long nwork = gnx > 0 ? (long long)ntx * nty * gS : (n + 63) >> 6;
+    const int gD = (gS + ND - 1) / ND; // depth groups per tile
+    const long long nwork = gnx > 0 ? (long long)ntx * nty * gD : (n + 64 * ND - 1) / (64 * ND);
 #ifdef VANERF_MESH_PHASES
     unsigned long long ph[16] = {}, tprev = __builtin_amdgcn_s_memtime();
 #endif
     for (long long w = claim(); w < nwork; w = claim()) {
         // every lane keeps a point (the searches below are wave-cooperative): a lane beyond the grid border / the end of the batch
         // repeats a neighbour's point and does not store
-        long long i;
-        bool act;
+        // sample index of depth k of this item for this lane, and whether the lane stores it (recomputed where needed rather than kept)
+        // (the item's depth group and pixel tile: wave-uniform, divided out once; the host checks that the item count fits 32 bits)
+        int item_d0 = 0, item_x0 = 0, item_y0 = 0;
         if (gnx > 0) {
-            const int d = (int)(w % gS);
-            const long long tile = w / gS;
-            const int tx = (int)(tile % ntx), ty = (int)(tile / ntx);
-            const int rx = tx * 8 + (lane & 7), ry = ty * 8 + (lane >> 3);
-            act = rx < gnx && ry < gny;
-            i = ((long long)min(ry, gny - 1) * gnx + min(rx, gnx - 1)) * gS + d;
-        } else {
-            i = w * 64 + lane;
-            act = i < n;
-            i = act ? i : n - 1;
+            const unsigned wu = (unsigned)w, tile = wu / (unsigned)gD;
+            item_d0 = __builtin_amdgcn_readfirstlane((int)(wu % (unsigned)gD) * ND);
+            item_x0 = __builtin_amdgcn_readfirstlane((int)(tile % (unsigned)ntx) * 8);
+            item_y0 = __builtin_amdgcn_readfirstlane((int)(tile / (unsigned)ntx) * 8);
         }
-        const f3 p = {P[3 * i], P[3 * i + 1], P[3 * i + 2]};
+        auto locate = [&](int k, bool& act) -> long long {
+            long long i;
+            if (gnx > 0) {
+                const int d = item_d0 + k;
+                const int rx = item_x0 + (lane & 7), ry = item_y0 + (lane >> 3);
+                act = rx < gnx && ry < gny && d < gS;
+                i = ((long long)min(ry, gny - 1) * gnx + min(rx, gnx - 1)) * gS + min(d, gS - 1);
+            } else {
+                i = (w * ND + k) * 64 + lane;
+                act = i < n;
+                i = act ? i : n - 1;
+            }
+            return i;
+        };
+        f3 pk[ND];
+#pragma unroll
+        for (int k = 0; k < ND; ++k) {
+            bool act;
+            const long long i = locate(k, act);
+            pk[k] = {P[3 * i], P[3 * i + 1], P[3 * i + 2]};
+        }
         MPH(0); // point load
         // ---- 1-NN vertex (knn_points K=1, src/networks.py:28): clusters of 16 Morton-sorted vertices; squared distance
         //      ((dx*dx + dy*dy) + dz*dz), first minimum in ORIGINAL vertex order (oracle/mesh_oracle.c:knn1)
@@ -372,27 +418,22 @@ __global__ __launch_bounds__(MA_BLOCK) void mesh_query_accel_kernel(const Vanerf
         // T than the largest bound any lane holds cannot matter to any lane.  The lanes test 64 clusters at a time against T (one
         // cluster per lane, __ballot), and only the surviving clusters are then tested by every lane against its own point and
         // bound -- the flat per-lane loop over all boxes this replaces was 2/3 of the kernel's instructions.
-        float tlo[3] = {p.x, p.y, p.z}, thi[3] = {p.x, p.y, p.z};
+        float tlo[3] = {pk[0].x, pk[0].y, pk[0].z}, thi[3] = {pk[0].x, pk[0].y, pk[0].z};
 #pragma unroll
-        for (int m = 32; m >= 1; m >>= 1)
+        for (int k = 1; k < ND; ++k) {
+            tlo[0] = fminf(tlo[0], pk[k].x); tlo[1] = fminf(tlo[1], pk[k].y); tlo[2] = fminf(tlo[2], pk[k].z);
+            thi[0] = fmaxf(thi[0], pk[k].x); thi[1] = fmaxf(thi[1], pk[k].y); thi[2] = fmaxf(thi[2], pk[k].z);
+        }
 #pragma unroll
-            for (int a = 0; a < 3; ++a) { tlo[a] = fminf(tlo[a], __shfl_xor(tlo[a], m)); thi[a] = fmaxf(thi[a], __shfl_xor(thi[a], m)); }
+        for (int a = 0; a < 3; ++a) { tlo[a] = wave_min_f(tlo[a]); thi[a] = wave_max_f(thi[a]); }
         auto tile_dist2 = [&](const float* b) { // box-to-box: <= box_dist2(q, b) for every q in T (same monotone fp32 expression)
             const float dx = fmaxf(fmaxf(b[0] - thi[0], tlo[0] - b[3]), 0.0f);
             const float dy = fmaxf(fmaxf(b[1] - thi[1], tlo[1] - b[4]), 0.0f);
             const float dz = fmaxf(fmaxf(b[2] - thi[2], tlo[2] - b[5]), 0.0f);
             return (dx * dx + dy * dy) + dz * dz;
         };
-        auto wave_max = [&](float v) {
-#pragma unroll
-            for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m));
-            return v;
-        };
-        auto wave_min = [&](float v) {
-#pragma unroll
-            for (int m = 32; m >= 1; m >>= 1) v = fminf(v, __shfl_xor(v, m));
-            return v;
-        };
+        auto wave_max = [&](float v) { return wave_max_f(v); };
+        auto wave_min = [&](float v) { return wave_min_f(v); };
         // ---- Tile searches.  With the ray-grid hint the 64 points of a wave lie within a few millimetres of each other -- less than a
         //      triangle -- so the wave first answers the query for ONE point, the centre tc of its tile, with the lanes working on 64
         //      CANDIDATES at a time (clusters, then the triangles / vertices of the surviving clusters), and only then every lane evaluates,
@@ -416,8 +457,13 @@ __global__ __launch_bounds__(MA_BLOCK) void mesh_query_accel_kernel(const Vanerf
         const f3 tc = {0.5f * (tlo[0] + thi[0]), 0.5f * (tlo[1] + thi[1]), 0.5f * (tlo[2] + thi[2])};
         float slack;
         {
-            const float ex = p.x - tc.x, ey = p.y - tc.y, ez = p.z - tc.z;
-            slack = 2.0f * sqrtf(wave_max((ex * ex + ey * ey) + ez * ez)) * (1.0f + 1e-5f) + 1e-5f;
+            float e2 = 0.0f;
+#pragma unroll
+            for (int k = 0; k < ND; ++k) {
+                const float ex = pk[k].x - tc.x, ey = pk[k].y - tc.y, ez = pk[k].z - tc.z;
+                e2 = fmaxf(e2, (ex * ex + ey * ey) + ez * ez);
+            }
+            slack = uni(2.0f * sqrtf(wave_max(e2)) * (1.0f + 1e-5f) + 1e-5f);
         }
         const float rho = 0.5f * slack;
         const bool try_tile = gnx > 0 && slack < 0.05f; // (a NaN slack compares false)
@@ -442,8 +488,10 @@ __global__ __launch_bounds__(MA_BLOCK) void mesh_query_accel_kernel(const Vanerf
             __builtin_amdgcn_wave_barrier();
             return ns;
         };
-        float vb = INFINITY;
-        int vi = 0x7fffffff;
+        float vbk[ND];
+        int vik[ND];
+#pragma unroll
+        for (int k = 0; k < ND; ++k) { vbk[k] = INFINITY; vik[k] = 0x7fffffff; }
         auto knn_tile = [&](int cm) -> bool { // cm: the vertex cluster nearest to tc
             float U = INFINITY;
             if (lane < CL) {
@@ -452,62 +500,104 @@ __global__ __launch_bounds__(MA_BLOCK) void mesh_query_accel_kernel(const Vanerf
                 U = (dx * dx + dy * dy) + dz * dz;
             }
             U = wave_min(U);
-            const int ns = collect(s_vbox, A.nvc, sq_plus(U));
-            if (ns > TL_LIST) return false;
+            int ns = collect(s_vbox, A.nvc, sq_plus(U));
+            if (ns > TL_LIST) {
+                // decimetres from the mesh every vertex cluster of the near side is within 2 rho of the minimum.  As for the faces below: the exact
+                // minimum at tc first (all vertices, from LDS), then only the clusters that can hold a vertex passing (ii) -- a vertex of cluster c
+                // lies in the ball around its box, so its unit vector differs from the box centre's by at most 1.05 R_c / |tc - m_c|.
+                float b = INFINITY;
+                int sb = 0;
+                for (int j = lane; j < A.nvc * CL; j += 64) {
+                    const float4 v = s_vs[j];
+                    const float dx = tc.x - v.x, dy = tc.y - v.y, dz = tc.z - v.z;
+                    const float d = (dx * dx + dy * dy) + dz * dz;
+                    if (d < b) { b = d; sb = j; }
+                }
+                const float D2a = wave_min(b), Da = sqrtf(D2a);
+                const unsigned long long mD = __ballot(b == D2a);
+                if (!mD || !(Da > 1e-4f)) return false;
+                const float4 va = s_vs[__builtin_amdgcn_readlane(sb, __builtin_ctzll(mD))];
+                const f3 ua = {(tc.x - va.x) / Da, (tc.y - va.y) / Da, (tc.z - va.z) / Da};
+                __builtin_amdgcn_wave_barrier();
+                ns = 0;
+                for (int c0 = 0; c0 < A.nvc; c0 += 64) {
+                    const int cl_ = min(c0 + lane, A.nvc - 1);
+                    const float* bx = s_vbox + 6 * cl_;
+                    const f3 e = {tc.x - 0.5f * (bx[0] + bx[3]), tc.y - 0.5f * (bx[1] + bx[4]), tc.z - 0.5f * (bx[2] + bx[5])};
+                    const float hx = bx[3] - bx[0], hy = bx[4] - bx[1], hz = bx[5] - bx[2];
+                    const float L = sqrtf(dot3(e, e)), x = (0.5f * sqrtf((hx * hx + hy * hy) + hz * hz) * (1.0f + 1e-5f) + 1e-7f) / fmaxf(L, 1e-20f);
+                    float du = 2.0f;
+                    if (x < 0.5f) {
+                        const float inv = 1.0f / fmaxf(L, 1e-20f);
+                        const float ex = e.x * inv - ua.x, ey = e.y * inv - ua.y, ez = e.z * inv - ua.z;
+                        du = sqrtf((ex * ex + ey * ey) + ez * ez) + 1.05f * x + 1e-5f;
+                    }
+                    const bool keep = c0 + lane < A.nvc && may_win(sqrtf(box_dist2(tc, bx)), Da, du, true);
+                    const unsigned long long m = __ballot(keep);
+                    const int pos = ns + mbcnt(m);
+                    if (keep && pos < TL_LIST) my_list[pos] = (unsigned short)cl_;
+                    ns += __builtin_popcountll(m);
+                }
+                __builtin_amdgcn_wave_barrier();
+                if (ns > TL_LIST) return false;
+            }
             const int nt = ns * CL;
-            float d_it[TL_IT];
-            int s_it[TL_IT];
+            float* const dit = s_dit[threadIdx.x >> 6][0] + lane; // round `it`, this lane: dit[it * 64]
+            // vertex slot number 64 it + lane of the listed clusters (the list stays in LDS; lanes beyond the list read an unused entry)
+            auto slot_of = [&](int it) { return (int)my_list[it * (64 / CL) + lane / CL] * CL + lane % CL; };
 #pragma unroll
             for (int it = 0; it < TL_IT; ++it) {
-                d_it[it] = INFINITY; s_it[it] = 0;
+                dit[it * 64] = INFINITY;
                 const int j = it * 64 + lane;
                 if (it * 64 < nt && j < nt) {
-                    const int slot = (int)my_list[j / CL] * CL + j % CL;
-                    const float4 v = s_vs[slot];
+                    const float4 v = s_vs[slot_of(it)];
                     const float dx = tc.x - v.x, dy = tc.y - v.y, dz = tc.z - v.z;
-                    d_it[it] = (dx * dx + dy * dy) + dz * dz;
-                    s_it[it] = slot;
+                    dit[it * 64] = (dx * dx + dy * dy) + dz * dz;
                 }
-                U = fminf(U, d_it[it]);
+                U = fminf(U, dit[it * 64]);
             }
-            const float D2 = wave_min(U), Tf = sq_plus(D2), D = sqrtf(D2);
+            const float D2 = uni(wave_min(U)), Tf = sq_plus(D2), D = sqrtf(D2);
             // reference: a vertex that attains the minimum at tc (always found: the seed cluster is on the list; if it ever were not, (i) alone decides)
             int slotD = 0;
             bool have = false;
 #pragma unroll
             for (int it = TL_IT - 1; it >= 0; --it) {
-                const unsigned long long m = (it * 64 < nt) ? __ballot(d_it[it] == D2) : 0ull;
-                if (m) { slotD = __builtin_amdgcn_readlane(s_it[it], __builtin_ctzll(m)); have = true; }
+                const unsigned long long m = (it * 64 < nt) ? __ballot(dit[it * 64] == D2) : 0ull;
+                if (m) { slotD = __builtin_amdgcn_readlane(slot_of(it), __builtin_ctzll(m)); have = true; }
             }
             const float4 vD = s_vs[slotD];
             const float invD = D > 1e-4f ? 1.0f / D : 0.0f;
-            const f3 uD = {(tc.x - vD.x) * invD, (tc.y - vD.y) * invD, (tc.z - vD.z) * invD};
+            const f3 uD = {uni((tc.x - vD.x) * invD), uni((tc.y - vD.y) * invD), uni((tc.z - vD.z) * invD)};
 #pragma unroll
             for (int it = 0; it < TL_IT; ++it) {
                 if (it * 64 < nt) {
-                    bool cand = d_it[it] <= Tf;
+                    bool cand = dit[it * 64] <= Tf;
                     if (cand) {
-                        const float4 v = s_vs[s_it[it]];
-                        const float d = sqrtf(d_it[it]), inv = 1.0f / fmaxf(d, 1e-20f);
+                        const float4 v = s_vs[slot_of(it)];
+                        const float d = sqrtf(dit[it * 64]), inv = 1.0f / fmaxf(d, 1e-20f);
                         const float ex = (tc.x - v.x) * inv - uD.x, ey = (tc.y - v.y) * inv - uD.y, ez = (tc.z - v.z) * inv - uD.z;
                         cand = may_win(d, D, sqrtf((ex * ex + ey * ey) + ez * ez), have);
                     }
                     unsigned long long m = __ballot(cand);
+                    const int sl = slot_of(it);
                     while (m) {
                         const int src = __builtin_ctzll(m);
                         m &= m - 1;
-                        const float4 v = s_vs[__builtin_amdgcn_readlane(s_it[it], src)];
-                        const float dx = p.x - v.x, dy = p.y - v.y, dz = p.z - v.z;
-                        const float d = (dx * dx + dy * dy) + dz * dz;
+                        const float4 v = s_vs[__builtin_amdgcn_readlane(sl, src)];
                         const int oi = __float_as_int(v.w);
-                        if (d < vb || (d == vb && oi < vi)) { vb = d; vi = oi; }
+#pragma unroll
+                        for (int k = 0; k < ND; ++k) {
+                            const float dx = pk[k].x - v.x, dy = pk[k].y - v.y, dz = pk[k].z - v.z;
+                            const float d = (dx * dx + dy * dy) + dz * dz;
+                            if (d < vbk[k] || (d == vbk[k] && oi < vik[k])) { vbk[k] = d; vik[k] = oi; }
+                        }
                     }
                 }
             }
             return true;
         };
         {
-            auto eval_v = [&](int c) {
+            auto eval_v = [&](const f3& p, float& vb, int& vi, int c) {
                 for (int k = 0; k < CL; ++k) {
                     const float4 v = s_vs[c * CL + k];
                     const float dx = p.x - v.x, dy = p.y - v.y, dz = p.z - v.z;
@@ -523,30 +613,37 @@ __global__ __launch_bounds__(MA_BLOCK) void mesh_query_accel_kernel(const Vanerf
                 const float lb = box_dist2(tc, s_vbox + 6 * c);
                 if (lb < smin) { smin = lb; cm = c; }
             }
-#pragma unroll
-            for (int m = 32; m >= 1; m >>= 1) {
-                const float o = __shfl_xor(smin, m);
-                const int oc = __shfl_xor(cm, m);
-                if (o < smin || (o == smin && oc < cm)) { smin = o; cm = oc; }
-            }
-            cm = __builtin_amdgcn_readfirstlane(cm);
+            cm = wave_min_i(smin == wave_min_f(smin) ? cm : 0x7fffffff); // the nearest box, the lowest cluster among equals
+            if (cm == 0x7fffffff) cm = 0;                                 // (a NaN tile)
             if (!(try_tile && knn_tile(cm))) { // per-lane search: every lane prunes against its own point and bound
-                vb = INFINITY; vi = 0x7fffffff;
-                eval_v(cm);
-                const float capw = wave_max(vb) * (1.0f + 1e-4f) + 1e-12f;
-                for (int c0 = 0; c0 < A.nvc; c0 += 64) {
-                    const int cl_ = c0 + lane;
-                    unsigned long long m = __ballot(cl_ < A.nvc && cl_ != cm && tile_dist2(s_vbox + 6 * min(cl_, A.nvc - 1)) <= capw);
-                    while (m) {
-                        const int c = c0 + __builtin_ctzll(m);
-                        m &= m - 1;
-                        if (box_dist2(p, s_vbox + 6 * c) > vb * (1.0f + 1e-4f) + 1e-12f) continue;
-                        eval_v(c);
+#pragma unroll
+                for (int k = 0; k < ND; ++k) {
+                    const f3 p = pk[k];
+                    float vb = INFINITY;
+                    int vi = 0x7fffffff;
+                    eval_v(p, vb, vi, cm);
+                    const float capw = wave_max(vb) * (1.0f + 1e-4f) + 1e-12f;
+                    for (int c0 = 0; c0 < A.nvc; c0 += 64) {
+                        const int cl_ = c0 + lane;
+                        unsigned long long m = __ballot(cl_ < A.nvc && cl_ != cm && tile_dist2(s_vbox + 6 * min(cl_, A.nvc - 1)) <= capw);
+                        while (m) {
+                            const int c = c0 + __builtin_ctzll(m);
+                            m &= m - 1;
+                            if (box_dist2(p, s_vbox + 6 * c) > vb * (1.0f + 1e-4f) + 1e-12f) continue;
+                            eval_v(p, vb, vi, c);
+                        }
                     }
+                    vbk[k] = vb;
+                    vik[k] = vi;
                 }
             }
-            if (vi == 0x7fffffff) vi = 0; // a NaN point compares false with everything: index 0, like the exhaustive scan
-            if (knn && act) knn[i] = vi;
+#pragma unroll
+            for (int k = 0; k < ND; ++k) {
+                if (vik[k] == 0x7fffffff) vik[k] = 0; // a NaN point compares false with everything: index 0, like the exhaustive scan
+                bool act;
+                const long long i = locate(k, act);
+                if (knn && act) knn[i] = vik[k];
+            }
         }
         MPH(1); // 1-NN
         // ---- closest face.  The nearest vertex belongs to some triangle, so its distance bounds the closest-face distance from
@@ -560,8 +657,10 @@ __global__ __launch_bounds__(MA_BLOCK) void mesh_query_accel_kernel(const Vanerf
         //      h^2 by 2 |h| delta <= kappa |e|^2 + w with w = 1e5 a^2 (tnorm.w); h^2 is lowered by that much where it adds
         //      to the bound and raised where it is subtracted.
         constexpr float kappa = 3e-5f;
-        float best = INFINITY;
-        int bf = 0x7fffffff;
+        float bestk[ND];
+        int bfk[ND];
+#pragma unroll
+        for (int k = 0; k < ND; ++k) { bestk[k] = INFINITY; bfk[k] = 0x7fffffff; }
         // disc lower bound (squared) of triangle t for point q
         auto disc_lb2 = [&](const float4 sp, const float4 tn, f3 q) {
             const float ex = q.x - sp.x, ey = q.y - sp.y, ez = q.z - sp.z;
@@ -573,7 +672,7 @@ __global__ __launch_bounds__(MA_BLOCK) void mesh_query_accel_kernel(const Vanerf
         };
         // The records of a cluster come through wave-uniform (scalar) loads: the cluster index is the same in every lane.  All CL bound
         // records are fetched before the first is used (one scalar-memory latency per cluster instead of one per triangle).
-        auto eval_cluster = [&](int c) {
+        auto eval_cluster = [&](const f3& p, float& best, int& bf, const float vb, int c) {
             float4 sp[CL], tn[CL];
 #pragma unroll
             for (int k = 0; k < CL; ++k) {
@@ -712,37 +811,37 @@ __global__ __launch_bounds__(MA_BLOCK) void mesh_query_accel_kernel(const Vanerf
             const int nt = ns * CL;
             // round `it`: lane l looks at triangle number 64 it + l of the listed clusters.  First the disc bounds of all rounds (their loads
             // are independent and overlap), then the exact distances at tc of the triangles whose bound is within the seed's threshold.
-            float d_it[TL_IT];
-            int t_it[TL_IT];
+            float* const dit = s_dit[threadIdx.x >> 6][0] + lane; // round `it`, this lane: dit[it * 64]
+            // triangle number 64 it + lane of the listed clusters (the list stays in LDS; lanes beyond the list read an unused entry)
+            auto tri_of = [&](int it) { return (int)my_list[it * (64 / CL) + lane / CL] * CL + lane % CL; };
 #pragma unroll
             for (int it = 0; it < TL_IT; ++it) {
-                d_it[it] = INFINITY; t_it[it] = 0;
+                dit[it * 64] = INFINITY;
                 const int j = it * 64 + lane;
                 if (it * 64 < nt && j < nt) {
-                    const int t = (int)my_list[j / CL] * CL + j % CL;
-                    t_it[it] = t;
+                    const int t = tri_of(it);
                     const float4 sp = reinterpret_cast<const float4*>(A.sphere)[t], tn = reinterpret_cast<const float4*>(A.tnorm)[t];
-                    d_it[it] = disc_lb2(sp, tn, tc) <= thr_eval ? 0.0f : INFINITY; // 0 = "evaluate me"
+                    dit[it * 64] = disc_lb2(sp, tn, tc) <= thr_eval ? 0.0f : INFINITY; // 0 = "evaluate me"
                 }
             }
 #pragma unroll
             for (int it = 0; it < TL_IT; ++it)
-                if (it * 64 < nt && d_it[it] == 0.0f) { const Tri T = load_tri(t_it[it]); d_it[it] = point_tri_dist2(tc, T.a, T.b, T.c); }
+                if (it * 64 < nt && dit[it * 64] == 0.0f) { const Tri T = load_tri(tri_of(it)); dit[it * 64] = point_tri_dist2(tc, T.a, T.b, T.c); }
 #pragma unroll
-            for (int it = 0; it < TL_IT; ++it) U = fminf(U, d_it[it]);
-            const float D2 = wave_min(U), Tf = sq_plus(D2), D = sqrtf(D2);
+            for (int it = 0; it < TL_IT; ++it) U = fminf(U, dit[it * 64]);
+            const float D2 = uni(wave_min(U)), Tf = sq_plus(D2), D = sqrtf(D2);
             // reference: (one of) the triangle(s) that attain the minimum at tc, with its closest point q_D
             int tD = cseed * CL;
             bool have = false;
 #pragma unroll
             for (int it = TL_IT - 1; it >= 0; --it) {
-                const unsigned long long m = (it * 64 < nt) ? __ballot(d_it[it] == D2) : 0ull;
-                if (m) { tD = __builtin_amdgcn_readlane(t_it[it], __builtin_ctzll(m)); have = true; }
+                const unsigned long long m = (it * 64 < nt) ? __ballot(dit[it * 64] == D2) : 0ull;
+                if (m) { tD = __builtin_amdgcn_readlane(tri_of(it), __builtin_ctzll(m)); have = true; }
             }
             f3 qD;
             { const Tri T = load_tri(tD); point_tri_dist2_q(tc, T.a, T.b, T.c, qD); }
             const float invD = D > 1e-4f ? 1.0f / D : 0.0f;
-            const f3 uD = {(tc.x - qD.x) * invD, (tc.y - qD.y) * invD, (tc.z - qD.z) * invD};
+            const f3 uD = {uni((tc.x - qD.x) * invD), uni((tc.y - qD.y) * invD), uni((tc.z - qD.z) * invD)};
             // the triangles that pass (i) get a second look (their closest point, for (ii)); those that pass both go to the wave's LDS
             // candidate table, from where every lane evaluates them for its own point
             float* const ctab = s_cand[threadIdx.x >> 6][0];
@@ -750,14 +849,14 @@ __global__ __launch_bounds__(MA_BLOCK) void mesh_query_accel_kernel(const Vanerf
             unsigned cbits = 0u; // bit `it`: this lane's triangle of round `it` is a candidate
 #pragma unroll
             for (int it = 0; it < TL_IT; ++it) {
-                if (it * 64 < nt && __ballot(d_it[it] <= Tf)) {
-                    bool cand = d_it[it] <= Tf;
+                if (it * 64 < nt && __ballot(dit[it * 64] <= Tf)) {
+                    bool cand = dit[it * 64] <= Tf;
                     Tri T = {};
                     if (cand) {
-                        T = load_tri(t_it[it]);
+                        T = load_tri(tri_of(it));
                         f3 qt;
                         point_tri_dist2_q(tc, T.a, T.b, T.c, qt);
-                        const float d = sqrtf(d_it[it]), inv = 1.0f / fmaxf(d, 1e-20f);
+                        const float d = sqrtf(dit[it * 64]), inv = 1.0f / fmaxf(d, 1e-20f);
                         const float ex = (tc.x - qt.x) * inv - uD.x, ey = (tc.y - qt.y) * inv - uD.y, ez = (tc.z - qt.z) * inv - uD.z;
                         cand = may_win(d, D, sqrtf((ex * ex + ey * ey) + ez * ez), have);
                     }
@@ -767,7 +866,7 @@ __global__ __launch_bounds__(MA_BLOCK) void mesh_query_accel_kernel(const Vanerf
                     if (cand && pos < TL_CAND) {
                         float* e = ctab + pos * 12;
                         e[0] = T.a.x; e[1] = T.a.y; e[2] = T.a.z; e[3] = T.b.x; e[4] = T.b.y; e[5] = T.b.z; e[6] = T.c.x; e[7] = T.c.y; e[8] = T.c.z;
-                        e[9] = __int_as_float(A.orig[t_it[it]]);
+                        e[9] = __int_as_float(A.orig[tri_of(it)]);
                     }
                     K += __builtin_popcountll(m);
                 }
@@ -788,7 +887,7 @@ __global__ __launch_bounds__(MA_BLOCK) void mesh_query_accel_kernel(const Vanerf
                         if (m) {
                             const int pos = k0 + mbcnt(m) - base;
                             if (((m >> lane) & 1ull) && pos >= 0 && pos < TL_CAND) {
-                                const int j = it * 64 + lane, t = (int)my_list[j / CL] * CL + j % CL; // (as in the rounds above: the list is still there)
+                                const int t = tri_of(it);
                                 const Tri T = load_tri(t);
                                 float* e = ctab + pos * 12;
                                 e[0] = T.a.x; e[1] = T.a.y; e[2] = T.a.z; e[3] = T.b.x; e[4] = T.b.y; e[5] = T.b.z; e[6] = T.c.x; e[7] = T.c.y; e[8] = T.c.z;
@@ -800,13 +899,22 @@ __global__ __launch_bounds__(MA_BLOCK) void mesh_query_accel_kernel(const Vanerf
                 }
                 __builtin_amdgcn_wave_barrier();
                 const int kn = min(TL_CAND, K - base);
-                for (int k = 0; k < kn; ++k) {
-                    const float4 e0 = reinterpret_cast<const float4*>(ctab + k * 12)[0], e1 = reinterpret_cast<const float4*>(ctab + k * 12)[1],
-                                 e2 = reinterpret_cast<const float4*>(ctab + k * 12)[2];
-                    const f3 a = {e0.x, e0.y, e0.z}, b = {e0.w, e1.x, e1.y}, c3 = {e1.z, e1.w, e2.x};
-                    const float d = point_tri_dist2(p, a, b, c3);
-                    const int of = __float_as_int(e2.y);
-                    if (d < best || (d == best && of < bf)) { best = d; bf = of; }
+#pragma unroll
+                for (int q = 0; q < ND; ++q) { // one point after the other: the registers of one exact distance at a time
+                    __builtin_amdgcn_sched_barrier(0);
+                    const f3 p = pk[q];
+                    float best = bestk[q];
+                    int bf = bfk[q];
+                    for (int k = 0; k < kn; ++k) {
+                        const float4 e0 = reinterpret_cast<const float4*>(ctab + k * 12)[0], e1 = reinterpret_cast<const float4*>(ctab + k * 12)[1],
+                                     e2 = reinterpret_cast<const float4*>(ctab + k * 12)[2];
+                        const f3 a = {e0.x, e0.y, e0.z}, b = {e0.w, e1.x, e1.y}, c3 = {e1.z, e1.w, e2.x};
+                        const float d = point_tri_dist2(p, a, b, c3);
+                        const int of = __float_as_int(e2.y);
+                        if (d < best || (d == best && of < bf)) { best = d; bf = of; }
+                    }
+                    bestk[q] = best;
+                    bfk[q] = bf;
                 }
             }
             return true;
@@ -819,40 +927,53 @@ __global__ __launch_bounds__(MA_BLOCK) void mesh_query_accel_kernel(const Vanerf
                 const float lb = box_dist2(tc, s_box + 6 * c);
                 if (lb < smin) { smin = lb; cseed = c; }
             }
-#pragma unroll
-            for (int m = 32; m >= 1; m >>= 1) {
-                const float o = __shfl_xor(smin, m);
-                const int oc = __shfl_xor(cseed, m);
-                if (o < smin || (o == smin && oc < cseed)) { smin = o; cseed = oc; }
-            }
-            cseed = __builtin_amdgcn_readfirstlane(cseed);
+            cseed = wave_min_i(smin == wave_min_f(smin) ? cseed : 0x7fffffff); // the nearest box, the lowest cluster among equals
+            if (cseed == 0x7fffffff) cseed = 0;                                 // (a NaN tile)
         }
         const bool tiled = try_tile && face_tile(cseed);
 #ifdef VANERF_MESH_PHASES
         if (lane == 0 && !try_tile) ph[13] += 1;
         if (lane == 0) { ph[tiled ? 8 : 9] += 1; const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (tiled) ph[10] += t_ - tprev; }
 #endif
-        if (!tiled) { best = INFINITY; bf = 0x7fffffff; eval_cluster(cseed); }
-        // (2) the other clusters: 64 at a time against T with the wave's largest bound, the survivors by every lane against its own
-        const float capf = wave_max(fminf(best, vb)) * (1.0f + 1e-4f) + 1e-12f;
-        for (int c0 = 0; c0 < (tiled ? 0 : A.nc); c0 += 64) {
-            const int cl_ = c0 + lane;
-            unsigned long long cm_ = __ballot(cl_ < A.nc && cl_ != cseed && tile_dist2(s_box + 6 * min(cl_, A.nc - 1)) <= capf);
-            while (cm_) {
-                const int c = c0 + __builtin_ctzll(cm_);
-                cm_ &= cm_ - 1;
+        if (!tiled) {
+#pragma unroll
+            for (int k = 0; k < ND; ++k) {
+                const f3 p = pk[k];
+                const float vb = vbk[k];
+                float best = INFINITY;
+                int bf = 0x7fffffff;
+                eval_cluster(p, best, bf, vb, cseed);
+                // (2) the other clusters: 64 at a time against T with the wave's largest bound, the survivors by every lane against its own
+                const float capf = wave_max(fminf(best, vb)) * (1.0f + 1e-4f) + 1e-12f;
+                for (int c0 = 0; c0 < A.nc; c0 += 64) {
+                    const int cl_ = c0 + lane;
+                    unsigned long long cm_ = __ballot(cl_ < A.nc && cl_ != cseed && tile_dist2(s_box + 6 * min(cl_, A.nc - 1)) <= capf);
+                    while (cm_) {
+                        const int c = c0 + __builtin_ctzll(cm_);
+                        cm_ &= cm_ - 1;
 #ifdef VANERF_MESH_PHASES
-                if (lane == 0) ph[5] += 1; // clusters surviving the wave-level test
+                        if (lane == 0) ph[5] += 1; // clusters surviving the wave-level test
 #endif
-                if (box_dist2(p, s_box + 6 * c) > fminf(best, vb) * (1.0f + 1e-4f) + 1e-12f) continue;
+                        if (box_dist2(p, s_box + 6 * c) > fminf(best, vb) * (1.0f + 1e-4f) + 1e-12f) continue;
 #ifdef VANERF_MESH_PHASES
-                if (__builtin_ctzll(__ballot(1)) == lane) ph[6] += 1; // ... whose triangles some lane looks at
+                        if (__builtin_ctzll(__ballot(1)) == lane) ph[6] += 1; // ... whose triangles some lane looks at
 #endif
-                eval_cluster(c);
+                        eval_cluster(p, best, bf, vb, c);
+                    }
+                }
+                bestk[k] = best;
+                bfk[k] = bf;
             }
         }
-        if (bf == 0x7fffffff) bf = 0; // NaN point (see above): never index the face table with the sentinel
         MPH(2); // closest face
+#pragma unroll
+        for (int k = 0; k < ND; ++k) {
+        __builtin_amdgcn_sched_barrier(0); // one point after the other (no interleaving of the unrolled copies: registers)
+        const f3 p = pk[k];
+        bool act;
+        const long long i = locate(k, act);
+        const float best = bestk[k];
+        const int bf = bfk[k] == 0x7fffffff ? 0 : bfk[k]; // NaN point (see above): never index the face table with the sentinel
         // inside test on the (y,z) grid
         int cnt = 0;
         {
@@ -899,6 +1020,7 @@ __global__ __launch_bounds__(MA_BLOCK) void mesh_query_accel_kernel(const Vanerf
         const float w0 = (1.0f - b1) - b2;
         const float sv = (w0 * vert_vis[i0] + b1 * vert_vis[i1]) + b2 * vert_vis[i2];
         if (act) vis[i] = sv >= 0.1f;
+        }
         MPH(4); // visibility + stores
     }
 #ifdef VANERF_MESH_PHASES
@@ -972,6 +1094,7 @@ extern "C" int vanerf_mesh_query_accel(const VanerfMeshAccel* accel, const float
         if (n == 0) return;
         if (grid_nx != 0 && (grid_nx < 0 || grid_ny <= 0 || grid_s <= 0 || (long long)grid_nx * grid_ny * grid_s != n))
             throw_error("vanerf_mesh_query_accel: ray-grid hint %d x %d x %d does not match n = %lld", grid_nx, grid_ny, grid_s, (long long)n);
+        if (n >= (1ll << 36)) throw_error("vanerf_mesh_query_accel: n = %lld points in one launch (limit 2^36)", (long long)n);
         // as many blocks as the chip holds at once (the work queue hands out the points); one of 64 queue slots per launch, zeroed on the stream
         static unsigned long long* const queue_base = [] {
             void* ptr = nullptr;
