@@ -13,7 +13,10 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
 # per-file flags.  query_kernel.hip: MFMA results are allocated in VGPRs (the chained layers read every accumulator element once with VALU
 # instructions; with the default AGPR form each read is a v_accvgpr_read first: 667 -> 95 per 32-sample group), and the SLP vectoriser
 # stays off (it packs adjacent f32 multiplies / adds into v_pk_* instructions, which cost more beside MFMAs than the scalar pairs).
-FILE_FLAGS = {"query_kernel.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-slp-vectorize"]}
+FILE_FLAGS = {"query_kernel.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-slp-vectorize"],
+              # mesh_query_accel_kernel sits exactly at 128 registers (four waves per SIMD): loop-invariant address arithmetic goes back into the
+              # work loop instead of being parked in scratch (7 spilled VGPRs without the flag; scratch fails the build, _check_no_scratch)
+              "mesh_kernels.hip": ["-mllvm", "-sink-insts-to-avoid-spills"]}
 
 
 def _stale():
@@ -22,12 +25,6 @@ def _stale():
     t = os.path.getmtime(LIB)
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "vanerf_hip.h"), __file__]
     return any(os.path.getmtime(d) > t for d in deps)
-
-
-# The one exception, in bytes per lane: mesh_query_accel_kernel at two depths per tile search and four waves per SIMD parks a few
-# loop-invariant address registers in scratch (stored once per wave, re-read once per 128 points).  Measured against the alternatives on
-# the benchmark view: 2.14 ms with these spills, 2.27 ms without them at three waves per SIMD, 2.61 ms at one depth per search.
-SCRATCH_ALLOWED = {"mesh_query_accel_kernel": 64}
 
 
 def _check_no_scratch(src, remarks):
@@ -40,7 +37,7 @@ def _check_no_scratch(src, remarks):
         if m:
             name = m.group(1)
         m = re.search(r"ScratchSize \[bytes/lane\]: (\d+)", line)
-        if m and int(m.group(1)) > max((v for k, v in SCRATCH_ALLOWED.items() if k in (name or "")), default=0):
+        if m and int(m.group(1)) > 0:
             bad.append((name, int(m.group(1))))
     if bad and os.environ.get("VANERF_ALLOW_SCRATCH") != "1":
         raise RuntimeError(f"{src}: kernels spill to scratch memory: {bad} (set VANERF_ALLOW_SCRATCH=1 to build anyway)")

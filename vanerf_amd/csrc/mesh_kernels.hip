@@ -291,7 +291,10 @@ constexpr int TL_IT = TL_LIST * CL / 64;
 #define VANERF_MA_ND 2
 #endif
 constexpr int ND = VANERF_MA_ND; // consecutive depths of a pixel tile a wave takes at once: one tile search, ND per-lane evaluations
-constexpr int TL_CAND = 40; // triangles (9 floats + original index, padded to 12) a wave's candidate table holds
+#ifndef VANERF_TL_CAND
+#define VANERF_TL_CAND 40
+#endif
+constexpr int TL_CAND = VANERF_TL_CAND; // triangles (9 floats + original index, padded to 12) a wave's candidate table holds
 static_assert(TL_LIST * CL % 64 == 0 && 64 % CL == 0 && MA_MAX_CLUSTERS <= 65536, "candidate lists hold 16-bit cluster ids in whole rounds of 64");
 
 // Diagnostic build only (-DVANERF_MESH_PHASES): s_memtime deltas per phase, summed over waves (tools/perf_mesh.py --phases)
@@ -364,6 +367,9 @@ __global__ __launch_bounds__(MA_BLOCK) VANERF_MA_ATTR void mesh_query_accel_kern
     // pixel tile: 64 points a few millimetres apart that prune almost identically.  Without the hint (gnx == 0) consecutive
     // lanes take consecutive samples (one whole ray per wave: its points span the bounding box, ~4x more work per wave).
     const int lane = threadIdx.x & 63;
+    // the lane number as a value the compiler must take afresh: index and address arithmetic on it is then redone where it is used instead of
+    // being hoisted out of the work loop into registers that stay occupied for the whole kernel (the kernel lives at the 128-register limit)
+    auto lane_now = [&]() { int l = lane; asm volatile("" : "+v"(l)); return l; };
     // Work queue: a wave claims its next 64 points with one atomic.  The cost of a wave's search varies 10x with the tile's distance from
     // the mesh; a fixed assignment left 40 % of the wave slots idle behind the slowest waves (2.45 of 4 waves per SIMD on average).
     auto claim = [&]() {
@@ -394,7 +400,8 @@ __global__ __launch_bounds__(MA_BLOCK) VANERF_MA_ATTR void mesh_query_accel_kern
             long long i;
             if (gnx > 0) {
                 const int d = item_d0 + k;
-                const int rx = item_x0 + (lane & 7), ry = item_y0 + (lane >> 3);
+                const int l = lane_now();
+                const int rx = item_x0 + (l & 7), ry = item_y0 + (l >> 3);
                 act = rx < gnx && ry < gny && d < gS;
                 i = ((long long)min(ry, gny - 1) * gnx + min(rx, gnx - 1)) * gS + min(d, gS - 1);
             } else {
@@ -478,7 +485,7 @@ __global__ __launch_bounds__(MA_BLOCK) VANERF_MA_ATTR void mesh_query_accel_kern
         auto collect = [&](const float* boxes, int ncl, float thr) {
             int ns = 0;
             for (int c0 = 0; c0 < ncl; c0 += 64) {
-                const int cl_ = c0 + lane;
+                const int cl_ = c0 + lane_now();
                 const bool keep = cl_ < ncl && box_dist2(tc, boxes + 6 * min(cl_, ncl - 1)) <= thr;
                 const unsigned long long m = __ballot(keep);
                 const int pos = ns + mbcnt(m);
@@ -507,7 +514,7 @@ __global__ __launch_bounds__(MA_BLOCK) VANERF_MA_ATTR void mesh_query_accel_kern
                 // lies in the ball around its box, so its unit vector differs from the box centre's by at most 1.05 R_c / |tc - m_c|.
                 float b = INFINITY;
                 int sb = 0;
-                for (int j = lane; j < A.nvc * CL; j += 64) {
+                for (int j = lane_now(); j < A.nvc * CL; j += 64) {
                     const float4 v = s_vs[j];
                     const float dx = tc.x - v.x, dy = tc.y - v.y, dz = tc.z - v.z;
                     const float d = (dx * dx + dy * dy) + dz * dz;
@@ -521,7 +528,7 @@ __global__ __launch_bounds__(MA_BLOCK) VANERF_MA_ATTR void mesh_query_accel_kern
                 __builtin_amdgcn_wave_barrier();
                 ns = 0;
                 for (int c0 = 0; c0 < A.nvc; c0 += 64) {
-                    const int cl_ = min(c0 + lane, A.nvc - 1);
+                    const int cl_ = min(c0 + lane_now(), A.nvc - 1);
                     const float* bx = s_vbox + 6 * cl_;
                     const f3 e = {tc.x - 0.5f * (bx[0] + bx[3]), tc.y - 0.5f * (bx[1] + bx[4]), tc.z - 0.5f * (bx[2] + bx[5])};
                     const float hx = bx[3] - bx[0], hy = bx[4] - bx[1], hz = bx[5] - bx[2];
@@ -544,7 +551,7 @@ __global__ __launch_bounds__(MA_BLOCK) VANERF_MA_ATTR void mesh_query_accel_kern
             const int nt = ns * CL;
             float* const dit = s_dit[threadIdx.x >> 6][0] + lane; // round `it`, this lane: dit[it * 64]
             // vertex slot number 64 it + lane of the listed clusters (the list stays in LDS; lanes beyond the list read an unused entry)
-            auto slot_of = [&](int it) { return (int)my_list[it * (64 / CL) + lane / CL] * CL + lane % CL; };
+            auto slot_of = [&](int it) { const int l = lane_now(); return (int)my_list[it * (64 / CL) + l / CL] * CL + l % CL; };
 #pragma unroll
             for (int it = 0; it < TL_IT; ++it) {
                 dit[it * 64] = INFINITY;
@@ -609,7 +616,7 @@ __global__ __launch_bounds__(MA_BLOCK) VANERF_MA_ATTR void mesh_query_accel_kern
             // seed: the vertex cluster nearest to the centre of T, evaluated by every lane
             float smin = INFINITY;
             int cm = 0;
-            for (int c = lane; c < A.nvc; c += 64) {
+            for (int c = lane_now(); c < A.nvc; c += 64) {
                 const float lb = box_dist2(tc, s_vbox + 6 * c);
                 if (lb < smin) { smin = lb; cm = c; }
             }
@@ -708,7 +715,7 @@ __global__ __launch_bounds__(MA_BLOCK) VANERF_MA_ATTR void mesh_query_accel_kern
             // a corner of it sticks out towards the tile by up to half its diagonal -- and lists every cluster of the near side.
             int ns = 0;
             for (int c0 = 0; c0 < A.nc; c0 += 64) {
-                const int cl_ = min(c0 + lane, A.nc - 1);
+                const int cl_ = min(c0 + lane_now(), A.nc - 1);
                 bool keep = c0 + lane < A.nc && box_dist2(tc, s_box + 6 * cl_) <= thr;
                 if (keep) {
                     const float4 cd = reinterpret_cast<const float4*>(A.cdisc)[2 * cl_], cn = reinterpret_cast<const float4*>(A.cdisc)[2 * cl_ + 1];
@@ -742,7 +749,7 @@ __global__ __launch_bounds__(MA_BLOCK) VANERF_MA_ATTR void mesh_query_accel_kern
                 auto list_clusters = [&](auto keep_fn) {
                     int n_ = 0;
                     for (int c0 = 0; c0 < A.nc; c0 += 64) {
-                        const int cl_ = min(c0 + lane, A.nc - 1);
+                        const int cl_ = min(c0 + lane_now(), A.nc - 1);
                         const bool keep = c0 + lane < A.nc && keep_fn(cl_);
                         const unsigned long long m = __ballot(keep);
                         const int pos = n_ + mbcnt(m);
@@ -759,7 +766,7 @@ __global__ __launch_bounds__(MA_BLOCK) VANERF_MA_ATTR void mesh_query_accel_kern
                 int t1 = cseed * CL;
                 if (lane < CL) { const Tri T = load_tri(cseed * CL + lane); b1 = point_tri_dist2(tc, T.a, T.b, T.c); t1 = cseed * CL + lane; }
                 if (n1 <= TL_LIST) {
-                    for (int j = lane; j < n1 * CL; j += 64) {
+                    for (int j = lane_now(); j < n1 * CL; j += 64) {
                         const int t = (int)my_list[j / CL] * CL + j % CL;
                         const float4 sp = reinterpret_cast<const float4*>(A.sphere)[t], tn = reinterpret_cast<const float4*>(A.tnorm)[t];
                         if (disc_lb2(sp, tn, tc) <= thr1) {
@@ -813,7 +820,7 @@ __global__ __launch_bounds__(MA_BLOCK) VANERF_MA_ATTR void mesh_query_accel_kern
             // are independent and overlap), then the exact distances at tc of the triangles whose bound is within the seed's threshold.
             float* const dit = s_dit[threadIdx.x >> 6][0] + lane; // round `it`, this lane: dit[it * 64]
             // triangle number 64 it + lane of the listed clusters (the list stays in LDS; lanes beyond the list read an unused entry)
-            auto tri_of = [&](int it) { return (int)my_list[it * (64 / CL) + lane / CL] * CL + lane % CL; };
+            auto tri_of = [&](int it) { const int l = lane_now(); return (int)my_list[it * (64 / CL) + l / CL] * CL + l % CL; };
 #pragma unroll
             for (int it = 0; it < TL_IT; ++it) {
                 dit[it * 64] = INFINITY;
@@ -923,7 +930,7 @@ __global__ __launch_bounds__(MA_BLOCK) VANERF_MA_ATTR void mesh_query_accel_kern
         int cseed = 0;
         {
             float smin = INFINITY;
-            for (int c = lane; c < A.nc; c += 64) {
+            for (int c = lane_now(); c < A.nc; c += 64) {
                 const float lb = box_dist2(tc, s_box + 6 * c);
                 if (lb < smin) { smin = lb; cseed = c; }
             }
