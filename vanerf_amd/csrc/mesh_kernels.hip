@@ -984,12 +984,17 @@ __global__ __launch_bounds__(MA_BLOCK) VANERF_MA_ATTR void mesh_query_accel_kern
         // inside test on the (y,z) grid
         int cnt = 0;
         {
-            int cy = (int)floorf((p.y - grid_y0) / grid_cy), cz = (int)floorf((p.z - grid_z0) / grid_cz);
+            const float fy = floorf((p.y - grid_y0) / grid_cy), fz = floorf((p.z - grid_z0) / grid_cz);
+            int cy = (int)fy, cz = (int)fz;
             cy = min(max(cy, 0), grid_G - 1);
             cz = min(max(cz, 0), grid_G - 1);
             const int cell = cy * grid_G + cz;
-            const int e = A.cell_start[cell + 1];
-            for (int k = A.cell_start[cell]; k < e; ++k) {
+            // A point more than a whole cell outside the mesh's (y,z) extent lies beside every triangle by ~1 mm or more: its edge functions
+            // (|edge| x distance against 1e-7 relative rounding) cannot all agree in sign, so the exhaustive scan counts no crossing either.
+            // (Points within a cell of the border keep going through the border cells' lists, as before.)
+            const bool beside = fy < -1.0f || fy > (float)grid_G || fz < -1.0f || fz > (float)grid_G;
+            const int e = beside ? 0 : A.cell_start[cell + 1];
+            for (int k = beside ? 0 : A.cell_start[cell]; k < e; ++k) {
                 const int f = A.cell_tri[k];
                 const int i0 = F[3 * f], i1 = F[3 * f + 1], i2 = F[3 * f + 2];
                 const f3 a = {V[3 * i0], V[3 * i0 + 1], V[3 * i0 + 2]}, b = {V[3 * i1], V[3 * i1 + 1], V[3 * i1 + 2]},
@@ -1103,18 +1108,23 @@ extern "C" int vanerf_mesh_query_accel(const VanerfMeshAccel* accel, const float
             throw_error("vanerf_mesh_query_accel: ray-grid hint %d x %d x %d does not match n = %lld", grid_nx, grid_ny, grid_s, (long long)n);
         if (n >= (1ll << 36)) throw_error("vanerf_mesh_query_accel: n = %lld points in one launch (limit 2^36)", (long long)n);
         // as many blocks as the chip holds at once (the work queue hands out the points); one of 64 queue slots per launch, zeroed on the stream
-        static unsigned long long* const queue_base = [] {
-            void* ptr = nullptr;
-            HIP_CHECK(hipGetSymbolAddress(&ptr, HIP_SYMBOL(g_ma_queue)));
-            return static_cast<unsigned long long*>(ptr);
-        }();
-        static const int resident = [&] {
-            int dev = 0, cus = 256, per_cu = 2;
-            HIP_CHECK(hipGetDevice(&dev));
+        struct PerDevice { std::atomic<unsigned long long*> queue{nullptr}; std::atomic<size_t> lds{0}; std::atomic<int> resident{0}; };
+        static PerDevice per_device[64]; // looked up once per device (and again when the mesh, hence the LDS footprint, changes)
+        int dev = 0;
+        HIP_CHECK(hipGetDevice(&dev));
+        PerDevice& pd = per_device[dev & 63];
+        if (pd.queue.load() == nullptr || pd.lds.load() != lds) {
+            int cus = 256, per_cu = 1;
+            void* qptr = nullptr;
+            HIP_CHECK(hipGetSymbolAddress(&qptr, HIP_SYMBOL(g_ma_queue)));
             HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
             HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mesh_query_accel_kernel, MA_BLOCK, lds));
-            return cus * (per_cu > 0 ? per_cu : 1);
-        }();
+            pd.resident.store(cus * (per_cu > 0 ? per_cu : 1));
+            pd.lds.store(lds);
+            pd.queue.store(static_cast<unsigned long long*>(qptr));
+        }
+        unsigned long long* const queue_base = pd.queue.load();
+        const int resident = pd.resident.load();
         static std::atomic<unsigned> next_slot{0};
         unsigned long long* const queue = queue_base + (next_slot.fetch_add(1u) % 64u);
         HIP_CHECK(hipMemsetAsync(queue, 0, sizeof(unsigned long long), (hipStream_t)stream));
@@ -1385,6 +1395,8 @@ __global__ __launch_bounds__(AB_THREADS) void accel_cell_scan_kernel(int G, int 
     if (total > capacity) { // the lists do not fit: one cell with every triangle
         if (threadIdx.x == 0) {
             grid[4] = __int_as_float(1);
+            grid[2] *= (float)G; // the one cell spans the whole extent (the query's "beside the mesh" test counts in cells)
+            grid[3] *= (float)G;
             cell_start[0] = 0;
             cell_start[1] = nf;
         }
