@@ -12,9 +12,15 @@ frame = synth.make_frame(seed=11, tar_h=512, tar_w=334, orbit_deg=15.0)
 fd = synth.to_device(frame, "cuda")
 sdd = {k: v.cuda() for k, v in sd.items() if k.startswith("tex_vis_fusion.")}
 fdat = R.FrameData(sdd, fd["img_in"], fd["feat_geo"], fd["feat_tex"], fd["src_foreground_mask"], fd["cam_in"], fd["targets"], fd["sp_data"])
-rays = R.ray_setup(frame["cam_tar"], frame["bounds"], 0, 0, 1, 334, 512, 64, device="cuda")
+NY = 512
+if "--share" in sys.argv:  # rank 0's rows of an N-GPU run (parallel.shard_rows): how the kernel does on a small launch
+    from vanerf_amd.parallel import shard_rows
+    y0, ys, NY, yb = shard_rows(512, int(sys.argv[sys.argv.index("--share") + 1]), 0)
+    rays = R.ray_setup(frame["cam_tar"], frame["bounds"], 0, y0, 1, 334, NY, 64, device="cuda", y_step=ys, y_block=yb)
+else:
+    rays = R.ray_setup(frame["cam_tar"], frame["bounds"], 0, 0, 1, 334, 512, 64, device="cuda")
 pts = R.sample_points(rays["rays_d"], rays["cam_pos"], rays["z"])
-for grid in ((334, 512, 64),) if "--hint-only" in sys.argv else ((334, 512, 64), None):
+for grid in ((334, NY, 64),) if "--hint-only" in sys.argv else ((334, NY, 64), None):
     ts = []
     for _ in range(4):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -31,7 +37,7 @@ if "--phases" in sys.argv:  # needs VANERF_HIPCC_FLAGS=-DVANERF_MESH_PHASES
     buf = (ctypes.c_uint64 * 16)()
     lib.vanerf_debug_mesh_phases.restype = ctypes.c_int
     lib.vanerf_debug_mesh_phases(buf, 1)
-    R.mesh_query_accel(fdat.accel, fdat.verts3, fdat.faces, fdat.vert_vis, pts, grid=(334, 512, 64)); torch.cuda.synchronize()
+    R.mesh_query_accel(fdat.accel, fdat.verts3, fdat.faces, fdat.vert_vis, pts, grid=(334, NY, 64)); torch.cuda.synchronize()
     lib.vanerf_debug_mesh_phases(buf, 1)
     tot = sum(buf[:5])
     for name, v in zip(["point load", "1-NN vertex", "closest face", "inside test", "visibility + stores"], buf):
