@@ -157,6 +157,7 @@ typedef struct {
     int nfp, nc;
     const int32_t* cell_start; /* [G*G + 1] CSR offsets of the (y,z) grid used by the inside test */
     const int32_t* cell_tri;   /* original face ids per cell */
+    const float* cell_rec;     /* [entries][12] the same lists as self-contained records: vertex ids i0 i1 i2 (int bits), corners a b c -- one load per entry in the inside test */
     const float* grid;         /* [5] DEVICE record of that grid: y0, z0, cell size in y, in z, G as int bits.  cell = clamp(floor((c - c0) / size), 0, G-1) */
     const float* vsort;        /* [nvc*CL][4] Morton-sorted vertices (xyz, original index as int bits), padded with far points */
     const float* vbox;         /* [nvc][6]    AABB of each cluster of CL vertices */
@@ -166,7 +167,7 @@ typedef struct {
                                 *           lies inside; second lower bound of the tile search of vanerf_mesh_query_accel (ray-grid hint) */
 } VanerfMeshAccel;
 
-/* Builds the tables above on the device, on `stream`, without a host synchronisation (six small launches; 0.1 ms for the two-hand MANO mesh):
+/* Builds the tables above on the device, on `stream`, without a host synchronisation (seven small launches; 0.1 ms for the two-hand MANO mesh):
  *     verts[NV][3], faces[NF][3] int32 (indices inside [0, NV): the caller's responsibility) -> *out, whose pointers point into `tables`,
  *     a caller-owned 16-byte-aligned device block of at least vanerf_mesh_accel_bytes(nv, nf, G, cell_capacity) bytes that must stay alive
  *     (and unmodified) for as long as *out is used.  G x G = cells of the (y,z) grid of the inside test (1..256; 64 for a hand mesh);

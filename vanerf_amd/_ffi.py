@@ -48,7 +48,7 @@ class VanerfFrame(Structure):
 class VanerfMeshAccel(Structure):
     _fields_ = [
         ("tri", _FP), ("sphere", _FP), ("tnorm", _FP), ("orig", _FP), ("cbox", _FP), ("nfp", c_int), ("nc", c_int),
-        ("cell_start", _FP), ("cell_tri", _FP), ("grid", _FP),
+        ("cell_start", _FP), ("cell_tri", _FP), ("cell_rec", _FP), ("grid", _FP),
         ("vsort", _FP), ("vbox", _FP), ("nvc", c_int), ("cdisc", _FP),
     ]
 

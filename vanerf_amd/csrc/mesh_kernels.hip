@@ -552,11 +552,13 @@ __global__ __launch_bounds__(MA_BLOCK) VANERF_MA_ATTR void mesh_query_accel_kern
             float* const dit = s_dit[threadIdx.x >> 6][0] + lane; // round `it`, this lane: dit[it * 64]
             // vertex slot number 64 it + lane of the listed clusters (the list stays in LDS; lanes beyond the list read an unused entry)
             auto slot_of = [&](int it) { const int l = lane_now(); return (int)my_list[it * (64 / CL) + l / CL] * CL + l % CL; };
-#pragma unroll
-            for (int it = 0; it < TL_IT; ++it) {
+            // (the rounds are run-time loops: their distances live in LDS, not in register arrays, and unrolled eight-fold they made the kernel
+            //  107 KB of code for a 64 KB instruction cache shared by two CUs)
+#pragma nounroll
+            for (int it = 0; it * 64 < nt; ++it) {
                 dit[it * 64] = INFINITY;
                 const int j = it * 64 + lane;
-                if (it * 64 < nt && j < nt) {
+                if (j < nt) {
                     const float4 v = s_vs[slot_of(it)];
                     const float dx = tc.x - v.x, dy = tc.y - v.y, dz = tc.z - v.z;
                     dit[it * 64] = (dx * dx + dy * dy) + dz * dz;
@@ -567,17 +569,17 @@ __global__ __launch_bounds__(MA_BLOCK) VANERF_MA_ATTR void mesh_query_accel_kern
             // reference: a vertex that attains the minimum at tc (always found: the seed cluster is on the list; if it ever were not, (i) alone decides)
             int slotD = 0;
             bool have = false;
-#pragma unroll
-            for (int it = TL_IT - 1; it >= 0; --it) {
-                const unsigned long long m = (it * 64 < nt) ? __ballot(dit[it * 64] == D2) : 0ull;
+#pragma nounroll
+            for (int it = 0; it * 64 < nt && !have; ++it) { // the first round that holds the minimum
+                const unsigned long long m = __ballot(dit[it * 64] == D2);
                 if (m) { slotD = __builtin_amdgcn_readlane(slot_of(it), __builtin_ctzll(m)); have = true; }
             }
             const float4 vD = s_vs[slotD];
             const float invD = D > 1e-4f ? 1.0f / D : 0.0f;
             const f3 uD = {uni((tc.x - vD.x) * invD), uni((tc.y - vD.y) * invD), uni((tc.z - vD.z) * invD)};
-#pragma unroll
-            for (int it = 0; it < TL_IT; ++it) {
-                if (it * 64 < nt) {
+#pragma nounroll
+            for (int it = 0; it * 64 < nt; ++it) {
+                {
                     bool cand = dit[it * 64] <= Tf;
                     if (cand) {
                         const float4 v = s_vs[slot_of(it)];
@@ -821,28 +823,28 @@ __global__ __launch_bounds__(MA_BLOCK) VANERF_MA_ATTR void mesh_query_accel_kern
             float* const dit = s_dit[threadIdx.x >> 6][0] + lane; // round `it`, this lane: dit[it * 64]
             // triangle number 64 it + lane of the listed clusters (the list stays in LDS; lanes beyond the list read an unused entry)
             auto tri_of = [&](int it) { const int l = lane_now(); return (int)my_list[it * (64 / CL) + l / CL] * CL + l % CL; };
-#pragma unroll
-            for (int it = 0; it < TL_IT; ++it) {
+#pragma nounroll
+            for (int it = 0; it * 64 < nt; ++it) {
                 dit[it * 64] = INFINITY;
                 const int j = it * 64 + lane;
-                if (it * 64 < nt && j < nt) {
+                if (j < nt) {
                     const int t = tri_of(it);
                     const float4 sp = reinterpret_cast<const float4*>(A.sphere)[t], tn = reinterpret_cast<const float4*>(A.tnorm)[t];
                     dit[it * 64] = disc_lb2(sp, tn, tc) <= thr_eval ? 0.0f : INFINITY; // 0 = "evaluate me"
                 }
             }
-#pragma unroll
-            for (int it = 0; it < TL_IT; ++it)
-                if (it * 64 < nt && dit[it * 64] == 0.0f) { const Tri T = load_tri(tri_of(it)); dit[it * 64] = point_tri_dist2(tc, T.a, T.b, T.c); }
-#pragma unroll
-            for (int it = 0; it < TL_IT; ++it) U = fminf(U, dit[it * 64]);
+#pragma nounroll
+            for (int it = 0; it * 64 < nt; ++it) {
+                if (dit[it * 64] == 0.0f) { const Tri T = load_tri(tri_of(it)); dit[it * 64] = point_tri_dist2(tc, T.a, T.b, T.c); }
+                U = fminf(U, dit[it * 64]);
+            }
             const float D2 = uni(wave_min(U)), Tf = sq_plus(D2), D = sqrtf(D2);
             // reference: (one of) the triangle(s) that attain the minimum at tc, with its closest point q_D
             int tD = cseed * CL;
             bool have = false;
-#pragma unroll
-            for (int it = TL_IT - 1; it >= 0; --it) {
-                const unsigned long long m = (it * 64 < nt) ? __ballot(dit[it * 64] == D2) : 0ull;
+#pragma nounroll
+            for (int it = 0; it * 64 < nt && !have; ++it) { // the first round that holds the minimum
+                const unsigned long long m = __ballot(dit[it * 64] == D2);
                 if (m) { tD = __builtin_amdgcn_readlane(tri_of(it), __builtin_ctzll(m)); have = true; }
             }
             f3 qD;
@@ -854,9 +856,9 @@ __global__ __launch_bounds__(MA_BLOCK) VANERF_MA_ATTR void mesh_query_accel_kern
             float* const ctab = s_cand[threadIdx.x >> 6][0];
             int K = 0;
             unsigned cbits = 0u; // bit `it`: this lane's triangle of round `it` is a candidate
-#pragma unroll
-            for (int it = 0; it < TL_IT; ++it) {
-                if (it * 64 < nt && __ballot(dit[it * 64] <= Tf)) {
+#pragma nounroll
+            for (int it = 0; it * 64 < nt; ++it) {
+                if (__ballot(dit[it * 64] <= Tf)) {
                     bool cand = dit[it * 64] <= Tf;
                     Tri T = {};
                     if (cand) {
@@ -878,6 +880,10 @@ __global__ __launch_bounds__(MA_BLOCK) VANERF_MA_ATTR void mesh_query_accel_kern
                     K += __builtin_popcountll(m);
                 }
             }
+#ifndef VANERF_TL_KMAX
+#define VANERF_TL_KMAX 100000
+#endif
+            if (K > VANERF_TL_KMAX) return false; // (a tile on the surface: every triangle within 2 rho is a candidate; the per-lane search prunes those by each lane's own bound)
 #ifdef VANERF_MESH_PHASES
             if (lane == 0 && K > TL_CAND) ph[15] += 1; // more candidates than the table holds: evaluated in batches
             if (lane == 0) ph[11] += K; // per-lane evaluations of the tile search
@@ -888,8 +894,8 @@ __global__ __launch_bounds__(MA_BLOCK) VANERF_MA_ATTR void mesh_query_accel_kern
                 if (base > 0) {
                     __builtin_amdgcn_wave_barrier(); // the previous batch's readers are done
                     int k0 = 0;
-#pragma unroll
-                    for (int it = 0; it < TL_IT; ++it) {
+#pragma nounroll
+                    for (int it = 0; it * 64 < nt; ++it) {
                         const unsigned long long m = __ballot((cbits >> it) & 1u);
                         if (m) {
                             const int pos = k0 + mbcnt(m) - base;
@@ -995,10 +1001,12 @@ __global__ __launch_bounds__(MA_BLOCK) VANERF_MA_ATTR void mesh_query_accel_kern
             const bool beside = fy < -1.0f || fy > (float)grid_G || fz < -1.0f || fz > (float)grid_G;
             const int e = beside ? 0 : A.cell_start[cell + 1];
             for (int k = beside ? 0 : A.cell_start[cell]; k < e; ++k) {
-                const int f = A.cell_tri[k];
-                const int i0 = F[3 * f], i1 = F[3 * f + 1], i2 = F[3 * f + 2];
-                const f3 a = {V[3 * i0], V[3 * i0 + 1], V[3 * i0 + 2]}, b = {V[3 * i1], V[3 * i1 + 1], V[3 * i1 + 2]},
-                         c3 = {V[3 * i2], V[3 * i2 + 1], V[3 * i2 + 2]};
+                // one 48-byte record per list entry (vertex ids for the canonical edge orientation, then the corners: copies of F and V), so that
+                // an entry costs one independent load instead of the chain face id -> vertex ids -> corners
+                const float4 r0 = reinterpret_cast<const float4*>(A.cell_rec)[3 * k], r1 = reinterpret_cast<const float4*>(A.cell_rec)[3 * k + 1],
+                             r2 = reinterpret_cast<const float4*>(A.cell_rec)[3 * k + 2];
+                const int i0 = __float_as_int(r0.x), i1 = __float_as_int(r0.y), i2 = __float_as_int(r0.z);
+                const f3 a = {r0.w, r1.x, r1.y}, b = {r1.z, r1.w, r2.x}, c3 = {r2.y, r2.z, r2.w};
                 float E0, E1, E2;
                 const bool s0 = edge_side(b, c3, i1, i2, p.y, p.z, E0);
                 const bool s1 = edge_side(c3, a, i2, i0, p.y, p.z, E1);
@@ -1094,7 +1102,7 @@ extern "C" int vanerf_mesh_query_accel(const VanerfMeshAccel* accel, const float
         if (n == 0) return; // an empty batch is valid (and has null data pointers)
         if (!accel || !verts || !faces || !vert_vis || !pts || !sdf || !vis) throw_error("vanerf_mesh_query_accel: null argument");
         const VanerfMeshAccel& A = *accel;
-        if (!A.tri || !A.sphere || !A.tnorm || !A.orig || !A.cbox || !A.cdisc || !A.cell_start || !A.cell_tri || !A.grid) throw_error("vanerf_mesh_query_accel: accel has a null pointer");
+        if (!A.tri || !A.sphere || !A.tnorm || !A.orig || !A.cbox || !A.cdisc || !A.cell_start || !A.cell_tri || !A.cell_rec || !A.grid) throw_error("vanerf_mesh_query_accel: accel has a null pointer");
         if (A.nc <= 0 || A.nc > MA_MAX_CLUSTERS || A.nfp != A.nc * CL || A.nfp < nf) throw_error("vanerf_mesh_query_accel: bad cluster table (nc=%d nfp=%d nf=%d)", A.nc, A.nfp, nf);
         if (nv <= 0 || nf <= 0 || n < 0) throw_error("vanerf_mesh_query_accel: nv=%d nf=%d n=%lld", nv, nf, (long long)n);
         if (!A.vsort || !A.vbox || A.nvc <= 0 || A.nvc > MA_MAX_VCLUSTERS || A.nvc * CL < nv)
@@ -1150,7 +1158,7 @@ extern "C" int vanerf_mesh_cluster_size(void) { return CL; }
 
 // ---------------------------------------------------------------------------------------------------------------
 // vanerf_mesh_accel_build: the tables of VanerfMeshAccel, built on the device without a host synchronisation (one per source frame).
-// Six small launches on the caller's stream:
+// Seven small launches on the caller's stream:
 //   bounds_sort   (2 blocks) vertex bounds -> grid record; Morton keys of triangle centroids (block 0) and of vertices (block 1), bitonic sort in LDS
 //   tables        per triangle cluster: sorted corners, bounding spheres / discs, cluster AABB and cylinder; per vertex cluster: vsort, vbox
 //   cell_count    per triangle: +1 in every (y,z) cell its bounding box touches
@@ -1158,6 +1166,7 @@ extern "C" int vanerf_mesh_cluster_size(void) { return CL; }
 //                 (the inside test then scans all of them: slower, same answer)
 //   cell_fill     per triangle: its id into the cells' lists (atomic cursors)
 //   cell_order    one wave per cell: ascending ids (a deterministic table whatever the order of the atomics)
+//   cell_record   per list entry: the triangle's vertex ids and corners, 48 bytes (what the inside test reads)
 // Every bound carries the slack of the fp32 arithmetic that produced it (1e-5 relative + 1e-6 of the largest coordinate), as the pruning
 // tests of mesh_query_accel_kernel assume.
 namespace {
@@ -1446,8 +1455,24 @@ __global__ __launch_bounds__(256) void accel_cell_order_kernel(int G, const floa
     }
 }
 
+// the cells' lists as self-contained records (see the inside test of mesh_query_accel_kernel)
+__global__ __launch_bounds__(256) void accel_cell_record_kernel(const float* __restrict__ V, const int32_t* __restrict__ F, const float* __restrict__ grid,
+                                                                const int32_t* __restrict__ cell_start, const int32_t* __restrict__ cell_tri,
+                                                                int capacity, float* __restrict__ cell_rec)
+{
+    const int e = blockIdx.x * 256 + threadIdx.x, Ge = __float_as_int(grid[4]); // (the grid in force: G, or 1 if it was degraded)
+    if (e >= capacity || e >= cell_start[Ge * Ge]) return;
+    const int f = cell_tri[e];
+    const int i0 = F[3 * f], i1 = F[3 * f + 1], i2 = F[3 * f + 2];
+    const f3 a = vert3(V, i0), b = vert3(V, i1), c = vert3(V, i2);
+    float4* r = reinterpret_cast<float4*>(cell_rec) + 3 * (size_t)e;
+    r[0] = make_float4(__int_as_float(i0), __int_as_float(i1), __int_as_float(i2), a.x);
+    r[1] = make_float4(a.y, a.z, b.x, b.y);
+    r[2] = make_float4(b.z, c.x, c.y, c.z);
+}
+
 struct AccelLayout {
-    size_t tri, sphere, tnorm, orig, cbox, cdisc, cell_start, cell_tri, grid, vsort, vbox, tri_order, vert_order, counts, unordered, total;
+    size_t tri, sphere, tnorm, orig, cbox, cdisc, cell_start, cell_tri, cell_rec, grid, vsort, vbox, tri_order, vert_order, counts, unordered, total;
     int nfp, nc, nvp, nvc;
 };
 
@@ -1465,6 +1490,7 @@ AccelLayout accel_layout(int nv, int nf, int G, int capacity)
     L.cdisc = take(sizeof(float) * 8 * L.nc);
     L.cell_start = take(sizeof(int32_t) * ((size_t)G * G + 1));
     L.cell_tri = take(sizeof(int32_t) * (size_t)capacity);
+    L.cell_rec = take(sizeof(float) * 12 * (size_t)capacity);
     L.grid = take(sizeof(float) * 8);
     L.vsort = take(sizeof(float) * 4 * L.nvp);
     L.vbox = take(sizeof(float) * 6 * L.nvc);
@@ -1539,10 +1565,13 @@ extern "C" int vanerf_mesh_accel_build(const float* verts, int nv, const int32_t
         hipLaunchKernelGGL(accel_cell_order_kernel, dim3((unsigned)((G * G + 3) / 4)), dim3(256), 0, st, G, F32(L.grid), I32(L.cell_start),
                            I32(L.unordered), I32(L.cell_tri));
         HIP_CHECK(hipGetLastError());
+        hipLaunchKernelGGL(accel_cell_record_kernel, dim3((unsigned)((cell_capacity + 255) / 256)), dim3(256), 0, st, verts, faces, F32(L.grid),
+                           I32(L.cell_start), I32(L.cell_tri), cell_capacity, F32(L.cell_rec));
+        HIP_CHECK(hipGetLastError());
         VanerfMeshAccel A{};
         A.tri = F32(L.tri), A.sphere = F32(L.sphere), A.tnorm = F32(L.tnorm), A.orig = I32(L.orig), A.cbox = F32(L.cbox), A.cdisc = F32(L.cdisc);
         A.nfp = L.nfp, A.nc = L.nc;
-        A.cell_start = I32(L.cell_start), A.cell_tri = I32(L.cell_tri), A.grid = F32(L.grid);
+        A.cell_start = I32(L.cell_start), A.cell_tri = I32(L.cell_tri), A.cell_rec = F32(L.cell_rec), A.grid = F32(L.grid);
         A.vsort = F32(L.vsort), A.vbox = F32(L.vbox), A.nvc = L.nvc;
         *out = A;
     });

@@ -200,7 +200,7 @@ def tex_global_vertex_feature(sd, feat_tex, img, pre="tex_vis_fusion."):
 
 class MeshAccel:
     """Per-frame acceleration structure of vanerf_mesh_query_accel: Morton-sorted triangle / vertex clusters with their bounds (closest-face
-    and 1-NN searches) and a (y,z) cell grid (inside test), built on the device by vanerf_mesh_accel_build -- six small launches on the
+    and 1-NN searches) and a (y,z) cell grid (inside test), built on the device by vanerf_mesh_accel_build -- seven small launches on the
     current stream, no host synchronisation (0.1 ms; the torch-op builder it replaces took 1.9 ms per source frame)."""
     CL = lib.vanerf_mesh_cluster_size()  # triangles / vertices per cluster the library was built with
 
