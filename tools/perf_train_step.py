@@ -6,7 +6,11 @@ from vanerf_amd import synth
 from vanerf_amd.config import default_config
 from vanerf_amd.model import VANeRF
 torch.manual_seed(0)
-net = VANeRF(default_config()).cuda().train()
+cfg = default_config()
+for key in ("grad_rays_per_chunk", "grad_samples_per_block"):  # e.g. --grad_samples_per_block 131072
+    if "--" + key in sys.argv:
+        cfg["models"]["VANeRF"][key] = int(sys.argv[sys.argv.index("--" + key) + 1])
+net = VANeRF(cfg).cuda().train()
 net.load_state_dict(synth.make_full_weights(0), strict=False)
 frame = synth.to_device(synth.make_frame(seed=3, tar_h=256, tar_w=256), "cuda")
 dr = {"img": frame["img_in"], "cam": frame["cam_in"], "cam_tar": frame["cam_tar"], "tar": torch.rand(1, 3, 256, 256, device="cuda"),

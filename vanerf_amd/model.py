@@ -469,7 +469,8 @@ class VANeRF(nn.Module):
                  "vert_vis": fd.vert_vis, "kpt3d": sp_data["kpt3d"], "extrin": sp_data["extrin"]}
         keys = [k for k in ("tex_fg", "depth", "alpha", "tex_fg_fine", "depth_fine", "alpha_fine", "sdf") if k in out]
         spec = {"values": [out[k] for k in keys], "keys": keys, "names": names, "frame": frame, "pass": o, "sp_args": self.kwargs["sp_args"],
-                "rays_per_chunk": self.kwargs.get("grad_rays_per_chunk", G.GRAD_RAYS_PER_CHUNK)}
+                "rays_per_chunk": self.kwargs.get("grad_rays_per_chunk", G.GRAD_RAYS_PER_CHUNK),
+                "samples_per_block": self.kwargs.get("grad_samples_per_block", G.GRAD_SAMPLES_PER_BLOCK)}
         for k, v in zip(keys, G.PassGradient.apply(spec, *leaves)):
             out[k] = v
         return out

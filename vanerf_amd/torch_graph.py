@@ -262,15 +262,18 @@ def networks_at(P, frame, pts, q_sdf, q_vis, knn, noise=None, sp_args=None):
         keep = mask.view(-1).nonzero().view(-1)
         if keep.numel() == mask.shape[0]:
             keep = None
-    sel = (lambda t: t) if keep is None else (lambda t: t.index_select(0, keep))
-    xy_k = sel(xy)
-    pix = [sample_map(f, xy_k) for f in frame["feat_geo"]]
-    fused = geo_fusion(P, frame["feat_geo"], pix, vert_xy, sel(knn), vis, sel(qv), sel(qs))
-    pe = positional_encoding(sel(pts), frame["kpt3d"], frame["extrin"], sp["sp_level"], sp["scale"], sp["sigma"])
-    geo, latent = geometry_mlp(P, pe, fused, sel(weight))
-    if keep is not None:
-        geo = torch.zeros(mask.shape[0], geo.shape[1], device=geo.device).index_copy(0, keep, geo)
-        latent = torch.zeros(mask.shape[0], latent.shape[1], device=latent.device).index_copy(0, keep, latent)
+    if keep is not None and keep.numel() == 0:  # a block without a valid sample: no geometry branch at all
+        geo, latent = torch.zeros(mask.shape[0], 2, device=pts.device), torch.zeros(mask.shape[0], 128, device=pts.device)
+    else:
+        sel = (lambda t: t) if keep is None else (lambda t: t.index_select(0, keep))
+        xy_k = sel(xy)
+        pix = [sample_map(f, xy_k) for f in frame["feat_geo"]]
+        fused = geo_fusion(P, frame["feat_geo"], pix, vert_xy, sel(knn), vis, sel(qv), sel(qs))
+        pe = positional_encoding(sel(pts), frame["kpt3d"], frame["extrin"], sp["sp_level"], sp["scale"], sp["sigma"])
+        geo, latent = geometry_mlp(P, pe, fused, sel(weight))
+        if keep is not None:
+            geo = torch.zeros(mask.shape[0], geo.shape[1], device=geo.device).index_copy(0, keep, geo)
+            latent = torch.zeros(mask.shape[0], latent.shape[1], device=latent.device).index_copy(0, keep, latent)
     latent24 = _Linear.apply(latent, P["ibr_compress_gfeat.weight"], P["ibr_compress_gfeat.bias"])
     table29 = frame.get("table29")
     if table29 is None:
@@ -305,6 +308,8 @@ def straight_through(value, graph):
 # whole patch 97 ms / 10.2 GiB, 2048 rays 115 ms / 5.4 GiB, 1024 rays 155 ms / 3.0 GiB, 512 rays 186 ms / 1.9 GiB.  With 288 GB of HBM the default is speed; model config key `grad_rays_per_chunk` sets it.
 # (bf16 operands for this graph's GEMMs were measured too: 106 ms, and the parameter gradients moved by 4e-2 relative -- dropped.)
 GRAD_RAYS_PER_CHUNK = None
+# Samples per block of the second stage of the backward pass (PassGradient); None = the coarse batch, then the fine batch, each whole.
+GRAD_SAMPLES_PER_BLOCK = None
 
 
 COMPACT_VALID = True  # networks_at: evaluate the geometry branch on valid samples only (tests compare both settings)
@@ -312,8 +317,10 @@ COMPACT_VALID = True  # networks_at: evaluate the geometry branch on valid sampl
 
 class PassGradient(torch.autograd.Function):
     """forward: the HIP pass's images, unchanged.  backward: the gradients of this module's graph at the samples of that pass with respect to
-    the leaves (the module's parameters and the encoders' feature maps), taken chunk of rays by chunk of rays: rays are independent, so the
-    gradient of the whole patch is the sum over chunks, and only one chunk's activations exist at a time.  The per-frame vertex table of
+    the leaves (the module's parameters and the encoders' feature maps), in two stages: the composites are differentiated at the pass's own
+    per-sample values (HIP), which gives the gradient with respect to every sample's network outputs; then the per-sample networks are
+    evaluated and differentiated block of samples by block (coarse batch, fine batch, optionally smaller blocks / chunks of rays): samples
+    are independent, so the gradient is the sum over blocks, and only one block's activations exist at a time.  The per-frame vertex table of
     TexVisFusion (two conv stacks over the source image) is shared by all samples: its graph is built once, the chunks accumulate the
     gradient with respect to the table, and one backward through the stacks closes the step."""
 
@@ -347,23 +354,20 @@ class PassGradient(torch.autograd.Function):
             step = spec["rays_per_chunk"] or R
             for r0 in range(0, R, step):
                 r1 = min(R, r0 + step)
-
-                def evaluate(part):
-                    S = part["pts"].shape[0] // R
-                    sl = slice(r0 * S, r1 * S)
-                    noise = None if part["noise"] is None else part["noise"][sl]
-                    return networks_at(P, dict(frame, table29=table), part["pts"][sl], part["q_sdf"].reshape(-1)[sl], part["q_vis"][sl],
-                                       part["knn"][sl].long(), noise, spec["sp_args"]).view(r1 - r0, S, 5)
-
-                rgba_c = evaluate(c)
-                col, dep, acc, _ = composite(P, rgba_c, o["z"][r0:r1], c["q_sdf"][r0:r1])
+                # (1) the composites, differentiated at the HIP pass's own per-sample values: a small graph over (rays, samples, 5) tensors that
+                #     yields the gradient with respect to every sample's [alpha, sdf, r, g, b] (and to sigmoid_beta)
+                rc = c["rgba"][r0:r1].detach().clone().requires_grad_(True)
+                col, dep, acc, _ = composite(P, rc, o["z"][r0:r1], c["q_sdf"][r0:r1])
                 outs = {"tex_fg": col, "depth": dep, "alpha": acc}
+                per_sample = [rc]
                 if f is not None:
-                    rgba_f, msdf = evaluate(f), f["q_sdf"][r0:r1]
+                    rf = f["rgba"][r0:r1].detach().clone().requires_grad_(True)
+                    per_sample.append(rf)
+                    rgba_f, msdf = rf, f["q_sdf"][r0:r1]
                     if o.get("fine_src") is not None:  # the pass re-used the coarse evaluations: merge [coarse | new] by the origin map
                         src = o["fine_src"][r0:r1].long()
-                        take = torch.where(src >= 0, src, rgba_c.shape[1] + (-src - 1))
-                        rgba_f = torch.gather(torch.cat([rgba_c, rgba_f], 1), 1, take[..., None].expand(-1, -1, 5))
+                        take = torch.where(src >= 0, src, rc.shape[1] + (-src - 1))
+                        rgba_f = torch.gather(torch.cat([rc, rf], 1), 1, take[..., None].expand(-1, -1, 5))
                         msdf = torch.gather(torch.cat([c["q_sdf"][r0:r1], f["q_sdf"][r0:r1]], 1), 1, take)
                     col, dep, acc, sdf = composite(P, rgba_f, o["z_fine"][r0:r1], msdf)
                     outs.update({"tex_fg_fine": col, "depth_fine": dep, "alpha_fine": acc, "sdf": sdf})
@@ -374,9 +378,27 @@ class PassGradient(torch.autograd.Function):
                     # images are (1,3,h,w) / (1,h,w) over the patch's rays in row-major order: the chunk's rays are a slice of the flattened image
                     gk = g.reshape(3, -1).t()[r0:r1] if k.startswith("tex_fg") else g.reshape(-1)[r0:r1]
                     pairs.append((outs[k], gk))
-                grads = torch.autograd.grad([a for a, _ in pairs], loc + [table], [b for _, b in pairs], allow_unused=True)
-                accumulate(grads[:-1])
-                if grads[-1] is not None:
-                    g_table += grads[-1]
+                grads = torch.autograd.grad([a for a, _ in pairs], per_sample + loc, [b for _, b in pairs], allow_unused=True)
+                accumulate(grads[len(per_sample):])
+                del outs, pairs, col, dep, acc
+                # (2) the per-sample networks, one block of samples after the other (samples are independent): only one block's graph exists at a
+                #     time, which is what bounds the step's memory -- the coarse and the fine batch are never alive together
+                for part, d_rgba in zip((c, f), grads[:len(per_sample)]):
+                    if d_rgba is None:
+                        continue
+                    S = part["pts"].shape[0] // R
+                    d_flat = d_rgba.reshape(-1, 5)
+                    n0, n1 = r0 * S, r1 * S
+                    block = spec.get("samples_per_block") or (n1 - n0)
+                    for b0 in range(n0, n1, block):
+                        sl = slice(b0, min(n1, b0 + block))
+                        noise = None if part["noise"] is None else part["noise"][sl]
+                        rgba = networks_at(P, dict(frame, table29=table), part["pts"][sl], part["q_sdf"].reshape(-1)[sl], part["q_vis"][sl],
+                                           part["knn"][sl].long(), noise, spec["sp_args"])
+                        g_block = torch.autograd.grad(rgba, loc + [table], d_flat[b0 - n0:b0 - n0 + rgba.shape[0]], allow_unused=True)
+                        del rgba
+                        accumulate(g_block[:-1])
+                        if g_block[-1] is not None:
+                            g_table += g_block[-1]
             accumulate(torch.autograd.grad(table_graph, loc, g_table, allow_unused=True))
         return (None, *total)
