@@ -302,11 +302,11 @@ def straight_through(value, graph):
     return graph + (value - graph).detach()
 
 
-# Rays per chunk of the backward pass (PassGradient); None = the whole patch at once.  The graph of a chunk lives only while its gradient is
-# taken, so chunking bounds the step's peak memory -- at the price of launch-bound kernels.  Measured on the 64x64 patch at 64 + 64 samples
-# (786 k samples, tools/perf_train_step.py, one MI355X, before the split-K / scatter kernels below took the whole-patch step from 97 to 62 ms):
-# whole patch 97 ms / 10.2 GiB, 2048 rays 115 ms / 5.4 GiB, 1024 rays 155 ms / 3.0 GiB, 512 rays 186 ms / 1.9 GiB.  With 288 GB of HBM the default is speed; model config key `grad_rays_per_chunk` sets it.
-# (bf16 operands for this graph's GEMMs were measured too: 106 ms, and the parameter gradients moved by 4e-2 relative -- dropped.)
+# Rays per chunk of the backward pass (PassGradient); None = the whole patch at once.  Chunking by rays repeats both stages per chunk; the block
+# size below bounds memory more cheaply (it only cuts the second stage).  Measured on the 64x64 patch at 64 + 64 samples (786 k samples,
+# tools/perf_train_step.py, one MI355X): whole patch 51 ms / 7.2 GiB; blocks of 262 144 samples 65 ms / 4.1 GiB; 131 072: 84 ms / 2.4 GiB;
+# 65 536: 107 ms / 1.6 GiB.  With 288 GB of HBM the default is speed; model config keys `grad_rays_per_chunk`, `grad_samples_per_block`.
+# (bf16 operands for this graph's GEMMs were measured too: 9 % faster, and the parameter gradients moved by 4e-2 relative -- dropped.)
 GRAD_RAYS_PER_CHUNK = None
 # Samples per block of the second stage of the backward pass (PassGradient); None = the coarse batch, then the fine batch, each whole.
 GRAD_SAMPLES_PER_BLOCK = None
