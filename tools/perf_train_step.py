@@ -6,6 +6,8 @@ from vanerf_amd import synth
 from vanerf_amd.config import default_config
 from vanerf_amd.model import VANeRF
 torch.manual_seed(0)
+import numpy as np
+np.random.seed(0)  # the training window is drawn with numpy (src/model.py:1172-1189): the same patches in every run
 cfg = default_config()
 for key in ("grad_rays_per_chunk", "grad_samples_per_block"):  # e.g. --grad_samples_per_block 131072
     if "--" + key in sys.argv:
