@@ -290,7 +290,7 @@ constexpr int TL_IT = TL_LIST * CL / 64;
 #ifndef VANERF_MA_ND
 #define VANERF_MA_ND 2
 #endif
-constexpr int ND = VANERF_MA_ND; // consecutive depths of a pixel tile a wave takes at once: one tile search, ND per-lane evaluations
+constexpr int ND_MAX = VANERF_MA_ND; // consecutive depths of a pixel tile a wave takes at once (template parameter ND of the kernel): one tile search, ND per-lane evaluations
 #ifndef VANERF_TL_CAND
 #define VANERF_TL_CAND 40
 #endif
@@ -340,6 +340,7 @@ __device__ __forceinline__ float box_dist2(f3 p, const float* b)
 #endif
 __device__ unsigned long long g_ma_queue[64]; // work-queue heads of mesh_query_accel_kernel, one per launch in flight (vanerf_mesh_query_accel)
 
+template <int ND> // 1 or ND_MAX: small launches take one depth per item (twice the items: a launch of a few thousand items is bound by the latency of single items)
 __global__ __launch_bounds__(MA_BLOCK) VANERF_MA_ATTR void mesh_query_accel_kernel(const VanerfMeshAccel A, const float* __restrict__ V,
                                                                     const int32_t* __restrict__ F, const float* __restrict__ vert_vis,
                                                                     const float* __restrict__ P, long long n, float* __restrict__ sdf,
@@ -1109,8 +1110,10 @@ extern "C" int vanerf_mesh_query_accel(const VanerfMeshAccel* accel, const float
             throw_error("vanerf_mesh_query_accel: bad vertex cluster table (nvc=%d nv=%d)", A.nvc, nv);
         const size_t lds = sizeof(float) * ((size_t)A.nvc * CL * 4 + (size_t)A.nvc * 6 + (size_t)A.nc * 6);
         if (lds > 140 * 1024) throw_error("vanerf_mesh_query_accel: mesh too large for the LDS-resident tables (%zu bytes)", lds);
-        if (lds > 64 * 1024) // above the default dynamic-LDS limit (gfx950 has 160 KB per CU)
-            HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(mesh_query_accel_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        if (lds > 64 * 1024) { // above the default dynamic-LDS limit (gfx950 has 160 KB per CU)
+            HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(mesh_query_accel_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(mesh_query_accel_kernel<ND_MAX>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        }
         if (n == 0) return;
         if (grid_nx != 0 && (grid_nx < 0 || grid_ny <= 0 || grid_s <= 0 || (long long)grid_nx * grid_ny * grid_s != n))
             throw_error("vanerf_mesh_query_accel: ray-grid hint %d x %d x %d does not match n = %lld", grid_nx, grid_ny, grid_s, (long long)n);
@@ -1126,7 +1129,7 @@ extern "C" int vanerf_mesh_query_accel(const VanerfMeshAccel* accel, const float
             void* qptr = nullptr;
             HIP_CHECK(hipGetSymbolAddress(&qptr, HIP_SYMBOL(g_ma_queue)));
             HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-            HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mesh_query_accel_kernel, MA_BLOCK, lds));
+            HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mesh_query_accel_kernel<ND_MAX>, MA_BLOCK, lds));
             pd.resident.store(cus * (per_cu > 0 ? per_cu : 1));
             pd.lds.store(lds);
             pd.queue.store(static_cast<unsigned long long*>(qptr));
@@ -1138,8 +1141,15 @@ extern "C" int vanerf_mesh_query_accel(const VanerfMeshAccel* accel, const float
         HIP_CHECK(hipMemsetAsync(queue, 0, sizeof(unsigned long long), (hipStream_t)stream));
         long long blocks = (n + MA_BLOCK - 1) / MA_BLOCK;
         if (blocks > resident) blocks = resident;
-        hipLaunchKernelGGL(mesh_query_accel_kernel, dim3((unsigned)blocks), dim3(MA_BLOCK), lds, (hipStream_t)stream, A, verts, faces, vert_vis,
-                           pts, (long long)n, sdf, vis, face, knn_idx, grid_nx, grid_ny, grid_s, queue);
+        // Several depths per item only when every wave gets a handful of them: below that a launch is bound by the latency of single items, and
+        // twice as many lighter items run better (a 128x128 view at 32 samples: 4 096 items of two depths for 4 096 waves).
+        const long long waves = (long long)resident * (MA_BLOCK / 64), items_nd = (n + 64 * ND_MAX - 1) / (64 * ND_MAX);
+        if (ND_MAX > 1 && items_nd >= 4 * waves)
+            hipLaunchKernelGGL(mesh_query_accel_kernel<ND_MAX>, dim3((unsigned)blocks), dim3(MA_BLOCK), lds, (hipStream_t)stream, A, verts, faces, vert_vis,
+                               pts, (long long)n, sdf, vis, face, knn_idx, grid_nx, grid_ny, grid_s, queue);
+        else
+            hipLaunchKernelGGL(mesh_query_accel_kernel<1>, dim3((unsigned)blocks), dim3(MA_BLOCK), lds, (hipStream_t)stream, A, verts, faces, vert_vis,
+                               pts, (long long)n, sdf, vis, face, knn_idx, grid_nx, grid_ny, grid_s, queue);
         HIP_CHECK(hipGetLastError());
     });
 }
