@@ -137,13 +137,15 @@ def test_training_step_under_detect_anomaly():
 
 
 def test_chunked_backward_gives_the_same_gradients():
-    """torch_graph.PassGradient takes the gradient chunk of rays by chunk of rays when `grad_rays_per_chunk` is set (bounded memory): the
-    sum over chunks is the gradient of the whole patch (rays are independent; the shared per-frame vertex table is closed once)."""
+    """torch_graph.PassGradient takes the gradient chunk of rays by chunk of rays when `grad_rays_per_chunk` is set, and the second stage of a
+    chunk block of samples by block when `grad_samples_per_block` is (bounded memory): the sum over chunks / blocks is the gradient of the
+    whole patch (rays and samples are independent; the shared per-frame vertex table is closed once)."""
     frame = synth.to_device(synth.make_frame(seed=3, tar_h=64, tar_w=64), "cuda")
     grads = []
-    for chunk in (None, 24):  # 64 rays: one chunk, then chunks of 24 + 24 + 16
+    for chunk, block in ((None, None), (24, None), (None, 200), (40, 96)):  # 64 rays: one chunk / chunks of 24 + 24 + 16 rays / blocks of 200 samples / both
         net = _net(0.01)
         net.kwargs["grad_rays_per_chunk"] = chunk
+        net.kwargs["grad_samples_per_block"] = block
         torch.manual_seed(3)
         import numpy as np
         np.random.seed(3)
@@ -151,10 +153,12 @@ def test_chunked_backward_gives_the_same_gradients():
         g = torch.Generator().manual_seed(1)
         sum((out[k] * torch.randn(out[k].shape, generator=g).cuda()).sum() for k in KEYS).backward()
         grads.append({k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None})
-    assert set(grads[0]) == set(grads[1]) and len(grads[0]) > 100
-    for k in grads[0]:
-        # fp32 sums in another order (a wiring error gives O(1)); a bias in front of a normalisation layer has a zero gradient up to rounding noise
-        assert (grads[0][k] - grads[1][k]).norm() <= 3e-3 * grads[0][k].norm() + 1e-4, k
+    assert len(grads[0]) > 100
+    for other in grads[1:]:
+        assert set(grads[0]) == set(other)
+        for k in grads[0]:
+            # fp32 sums in another order (a wiring error gives O(1)); a bias in front of a normalisation layer has a zero gradient up to rounding noise
+            assert (grads[0][k] - other[k]).norm() <= 3e-3 * grads[0][k].norm() + 1e-4, k
 
 
 def test_geometry_branch_on_valid_samples_only_gives_the_same_gradients():
