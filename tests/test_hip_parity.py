@@ -866,6 +866,39 @@ def test_one_call_pass_equals_the_python_sequence(R, sd_full, precision):
     torch.cuda.synchronize()
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_training_noise_keeps_the_coarse_reuse(R, sd_full, precision):
+    """rand_noise_std > 0 (training): the reference evaluates the coarse points again inside the fine batch, with fresh draws added to the
+    networks' OUTPUT (eval_func, src/model.py:1155-1156).  The pass evaluates the networks once per point (raw outputs) and applies eval_func
+    with either set of draws: every output must carry the same bits as the pass that re-evaluates all Sc + Sf samples with the same draws --
+    through the Python sequence, given draws and a seeded generator, and against the one-call C pass."""
+    frame = _frame(3, 64)
+    fdat = _frame_data(R, sd_full, frame)
+    w = R.PackedWeights(sd_full, mode=precision)
+    nx = ny = 24
+    Sc, Sf = 16, 16
+    g = torch.Generator().manual_seed(5)
+    draws = (torch.randn(nx * ny * Sc, generator=g).cuda(), torch.randn(nx * ny * (Sc + Sf), generator=g).cuda())
+    jit = torch.rand(nx * ny, Sc, generator=g).cuda()
+    u = torch.rand(nx * ny, Sf, generator=g).cuda()
+    kw = dict(jitter=jit, u=u, noise_std=0.05)
+    a = R.render_pass(w, fdat, frame["cam_tar"], frame["bounds"], 7, 9, 2, nx, ny, Sc, Sf, noise_draws=draws, debug=True, **kw)
+    b = R.render_pass(w, fdat, frame["cam_tar"], frame["bounds"], 7, 9, 2, nx, ny, Sc, Sf, noise_draws=draws, reuse_coarse=False, debug=True, **kw)
+    c = R.render_pass_c(w, fdat, frame["cam_tar"], frame["bounds"], 7, 9, 2, nx, ny, Sc, Sf, noise_draws=draws, **kw)
+    assert a["fine_src"] is not None and a["coarse_in_fine"] is not None and b["fine_src"] is None
+    assert a["fine"]["pts"].shape[0] == nx * ny * Sf and b["fine"]["pts"].shape[0] == nx * ny * (Sc + Sf)
+    for k in ("color", "depth", "alpha", "color_fine", "depth_fine", "alpha_fine", "sdf", "z_fine"):
+        assert torch.equal(a[k], b[k]), k
+        assert torch.equal(a[k], c[k]), k
+    assert (a["coarse"]["rgba"][..., 0] != a["coarse_in_fine"]["rgba"][..., 0]).float().mean() > 0.05  # the two sets of draws differ where alpha > 0
+    ga, gb = torch.Generator(device="cuda").manual_seed(11), torch.Generator(device="cuda").manual_seed(11)
+    d = R.render_pass(w, fdat, frame["cam_tar"], frame["bounds"], 7, 9, 2, nx, ny, Sc, Sf, generator=ga, **kw)
+    e = R.render_pass(w, fdat, frame["cam_tar"], frame["bounds"], 7, 9, 2, nx, ny, Sc, Sf, generator=gb, reuse_coarse=False, **kw)
+    for k in ("color", "color_fine", "alpha_fine", "sdf"):
+        assert torch.equal(d[k], e[k]), k
+    assert not torch.equal(d["color_fine"], a["color_fine"])
+
+
 def test_scatter_add_rows(R):
     """vanerf_scatter_add_rows (backward of the row gathers of a training step) against torch.index_add_: tables of 1 024 x 64, 16 384 x 8 and
     1 558 x 29 rows x channels, heavy index duplication, optional per-sample weights, out-of-range rows ignored, accumulation into a non-zero table."""

@@ -540,8 +540,11 @@ def render_pass(weights, frame, cam_tar, bounds, x0, y0, step, nx, ny, sample_pe
     reuse_coarse: the fine composite needs the networks at the Sc coarse and the Sf new depths of every ray.  The reference
     evaluates all Sc+Sf again (src/model.py:1305-1345); the per-sample networks are pure functions of the position, so by
     default only the Sf new samples are evaluated and the coarse results are merged in by depth (same bits, 1/3 less work).
-    With per-sample noise (training, rand_noise_std > 0) the reference draws fresh noise for the re-evaluated coarse
-    samples, so re-use is switched off there."""
+    With per-sample noise (training, rand_noise_std > 0) the reference draws fresh noise for the re-evaluated coarse samples -- but the
+    noise is added to the networks' output (rad += randn * std, eval_func, src/model.py:1155-1156), not to their input, and with one source
+    view nothing else is random in VANeRF.query (the view dropout of 804-810 needs n_views > 1): the networks are evaluated once per point
+    here too (raw outputs + validity), and eval_func is applied twice to the coarse points, with the coarse pass's draws and with the draws
+    the fine batch holds at their sorted positions.  Same bits as re-evaluating (tests/test_hip_parity.py), 1/3 less work."""
     Sc, Sf = int(sample_per_ray_c), int(sample_per_ray_f)
     rays = ray_setup(cam_tar, bounds, x0, y0, step, nx, ny, Sc, jitter=jitter, device=frame.verts3.device, y_step=y_step, pixels=pixels,
                      y_block=y_block)
@@ -552,30 +555,51 @@ def render_pass(weights, frame, cam_tar, bounds, x0, y0, step, nx, ny, sample_pe
                 if inject[k].shape != rays[k].shape or inject[k].dtype != torch.float32:
                     raise ValueError(f"inject[{k!r}] must be float32 of shape {tuple(rays[k].shape)}")
                 rays[k] = inject[k].contiguous()
-    if noise_std > 0.0 or (inject is not None and "z_fine" in inject):
+    if inject is not None and "z_fine" in inject:
         reuse_coarse = False
+    noisy_reuse = noise_std > 0.0 and fine and reuse_coarse  # raw network outputs, eval_func (noise, mask) applied here
     if noise_draws is not None and (noise_draws[0].numel() != R * Sc or (fine and noise_draws[1].numel() != R * (Sc + Sf))):
         raise ValueError("noise_draws: one draw per evaluated sample (R*Sc coarse, R*(Sc+Sf) fine)")
 
-    def evaluate(z, draws=None):
+    def scaled(draws, n):  # th.randn_like(rad) * rand_noise_std (src/model.py:1155-1156), drawn on the device (or handed in)
+        dev = frame.verts3.device
+        draws = torch.randn(n, device=dev, generator=generator) if draws is None else draws.reshape(-1).to(dev, torch.float32)
+        return (draws * noise_std).contiguous()
+
+    def eval_func(raw, valid, noise):
+        """src/model.py:1140-1160 on the kernel's raw outputs [sdf_pred, rad, r, g, b]: the same fp32 operations in the same order as the
+        kernel's own epilogue (csrc/query_kernel.hip), so the same bits."""
+        mask = valid.to(torch.float32)
+        alpha = mask * torch.clamp_min(raw[:, 1] + noise, 0.0)
+        sdf = mask * raw[:, 0] + (1.0 - mask) * float(frame.c.invalid_sdf)
+        return torch.stack([alpha, sdf, raw[:, 2], raw[:, 3], raw[:, 4]], 1).contiguous()
+
+    def evaluate(z, draws=None, raw=False):
         pts = sample_points(rays["rays_d"], rays["cam_pos"], z)
         grid = (nx, ny, z.shape[1]) if pixels is None else None
         q_sdf, q_vis, knn = mesh_query_accel(frame.accel, frame.verts3, frame.faces, frame.vert_vis, pts, grid=grid)
-        noise = None
-        if noise_std > 0.0:  # th.randn_like(rad) * rand_noise_std (src/model.py:1155-1156), drawn on the device
-            draws = torch.randn(pts.shape[0], device=pts.device, generator=generator) if draws is None else draws.reshape(-1).to(pts.device, torch.float32)
-            noise = (draws * noise_std).contiguous()
+        noise = scaled(draws, pts.shape[0]) if noise_std > 0.0 and not raw else None
         order = query_order(frame, pts) if pts.shape[0] >= PARTITION_MIN_SAMPLES else None
         if kernel_events is not None:  # HIP events around the dominant kernel alone (the partition kernels are outside), on the stream it is launched on
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        rgba = query_samples(weights, frame, pts, q_sdf, q_vis, knn, noise, order=order)
+        res = query_samples(weights, frame, pts, q_sdf, q_vis, knn, noise, order=order, raw=raw, want_valid=raw)
         if kernel_events is not None:
             e1.record()
             kernel_events.append((e0, e1, pts.shape[0]))
-        return dict(pts=pts, q_sdf=q_sdf.view(R, -1), q_vis=q_vis, knn=knn, noise=noise, rgba=rgba.view(R, -1, 5))
+        d = dict(pts=pts, q_sdf=q_sdf.view(R, -1), q_vis=q_vis, knn=knn, noise=noise)
+        if raw:
+            d["raw"], d["valid"] = res
+        else:
+            d["rgba"] = res.view(R, -1, 5)
+        return d
 
-    c = evaluate(rays["z"], None if noise_draws is None else noise_draws[0])
+    if noisy_reuse:
+        c = evaluate(rays["z"], raw=True)
+        c["noise"] = scaled(None if noise_draws is None else noise_draws[0], R * Sc)
+        c["rgba"] = eval_func(c["raw"], c["valid"], c["noise"]).view(R, Sc, 5)
+    else:
+        c = evaluate(rays["z"], None if noise_draws is None else noise_draws[0])
     c["color"], c["depth"], c["alpha"], c["contrib"], c["sdf"] = composite(c["rgba"], rays["z"], c["q_sdf"], weights.beta)
     out = {"color": c["color"], "depth": c["depth"], "alpha": c["alpha"], "index": rays["index"], "z": rays["z"], "hit": rays["hit"],
            "rays_d": rays["rays_d"], "cam_pos": rays["cam_pos"]}
@@ -588,7 +612,20 @@ def render_pass(weights, frame, cam_tar, bounds, x0, y0, step, nx, ny, sample_pe
                 raise ValueError("inject['z_fine'] must have shape (R, Sc + Sf)")
         else:
             z_new, z_fine, src = importance_merge(c["contrib"], rays["z"], Sf, u=u)
-        if reuse_coarse:
+        cf = None
+        if noisy_reuse:
+            # position of every coarse / new sample in the fine batch's sorted order: src[r][j] >= 0 is a coarse sample id, < 0 is ~(new sample id)
+            ids = torch.where(src >= 0, src, Sc + (-src - 1)).long()
+            pos = torch.empty_like(ids).scatter_(1, ids, torch.arange(Sc + Sf, device=ids.device).expand(R, -1))
+            noise_f = scaled(None if noise_draws is None else noise_draws[1], R * (Sc + Sf)).view(R, Sc + Sf)
+            f = evaluate(z_new, raw=True)
+            f["noise"] = noise_f.gather(1, pos[:, Sc:]).reshape(-1).contiguous()
+            f["rgba"] = eval_func(f["raw"], f["valid"], f["noise"]).view(R, Sf, 5)
+            cf = {"noise": noise_f.gather(1, pos[:, :Sc]).reshape(-1).contiguous()}  # the coarse points as the fine batch sees them
+            cf["rgba"] = eval_func(c["raw"], c["valid"], cf["noise"]).view(R, Sc, 5)
+            f["color"], f["depth"], f["alpha"], f["contrib"], f["sdf"] = composite_merged(cf["rgba"], c["q_sdf"], f["rgba"], f["q_sdf"], src,
+                                                                                          z_fine, weights.beta, want_contrib=debug)
+        elif reuse_coarse:
             f = evaluate(z_new)
             f["color"], f["depth"], f["alpha"], f["contrib"], f["sdf"] = composite_merged(c["rgba"], c["q_sdf"], f["rgba"], f["q_sdf"], src,
                                                                                           z_fine, weights.beta, want_contrib=debug)
@@ -599,6 +636,7 @@ def render_pass(weights, frame, cam_tar, bounds, x0, y0, step, nx, ny, sample_pe
         if debug:
             out["fine"] = f
             out["fine_src"] = src if reuse_coarse else None
+            out["coarse_in_fine"] = cf  # (noise, rgba) of the coarse points inside the fine batch when they carry other draws there; else None
     return out
 
 

@@ -279,10 +279,15 @@ def networks_at(P, frame, pts, q_sdf, q_vis, knn, noise=None, sp_args=None):
     if table29 is None:
         table29 = texture_vertex_table(P, vert_xy, frame["feat_tex"], frame["img"])
     rgb = texture_fusion(P, table29, sample_map(frame["feat_tex"], xy), sample_map(frame["img"], xy), knn, vis, qv, latent24)[:, :3]
-    # eval_func (src/model.py:1140-1160)
+    # eval_func (src/model.py:1140-1160); a tuple of noise vectors gives a tuple of outputs that share the networks' evaluation (the coarse
+    # points of a training pass appear in the coarse and in the fine composite with different draws)
     sdf = mask * geo[:, 0:1] + (1.0 - mask) * (0.1 / cam["nml_scale"])
-    rad = geo[:, 1:2] if noise is None else geo[:, 1:2] + noise.view(-1, 1)
-    return torch.cat([mask * torch.relu(rad), sdf, rgb], -1)
+
+    def with_noise(nz):
+        rad = geo[:, 1:2] if nz is None else geo[:, 1:2] + nz.view(-1, 1)
+        return torch.cat([mask * torch.relu(rad), sdf, rgb], -1)
+
+    return tuple(with_noise(nz) for nz in noise) if isinstance(noise, tuple) else with_noise(noise)
 
 
 def composite(P, rgba, z, mesh_sdf):
@@ -308,7 +313,7 @@ def straight_through(value, graph):
 # 65 536: 107 ms / 1.6 GiB.  With 288 GB of HBM the default is speed; model config keys `grad_rays_per_chunk`, `grad_samples_per_block`.
 # (bf16 operands for this graph's GEMMs were measured too: 9 % faster, and the parameter gradients moved by 4e-2 relative -- dropped.)
 GRAD_RAYS_PER_CHUNK = None
-# Samples per block of the second stage of the backward pass (PassGradient); None = the coarse batch, then the fine batch, each whole.
+# Samples per block of the second stage of the backward pass (PassGradient); None = all samples of a chunk of rays in one block.
 GRAD_SAMPLES_PER_BLOCK = None
 
 
@@ -360,6 +365,7 @@ class PassGradient(torch.autograd.Function):
                 col, dep, acc, _ = composite(P, rc, o["z"][r0:r1], c["q_sdf"][r0:r1])
                 outs = {"tex_fg": col, "depth": dep, "alpha": acc}
                 per_sample = [rc]
+                cf = o.get("coarse_in_fine") if f is not None else None
                 if f is not None:
                     rf = f["rgba"][r0:r1].detach().clone().requires_grad_(True)
                     per_sample.append(rf)
@@ -367,7 +373,11 @@ class PassGradient(torch.autograd.Function):
                     if o.get("fine_src") is not None:  # the pass re-used the coarse evaluations: merge [coarse | new] by the origin map
                         src = o["fine_src"][r0:r1].long()
                         take = torch.where(src >= 0, src, rc.shape[1] + (-src - 1))
-                        rgba_f = torch.gather(torch.cat([rc, rf], 1), 1, take[..., None].expand(-1, -1, 5))
+                        rcf = rc
+                        if cf is not None:  # (training noise: the coarse points carry other draws inside the fine batch)
+                            rcf = cf["rgba"][r0:r1].detach().clone().requires_grad_(True)
+                            per_sample.append(rcf)
+                        rgba_f = torch.gather(torch.cat([rcf, rf], 1), 1, take[..., None].expand(-1, -1, 5))
                         msdf = torch.gather(torch.cat([c["q_sdf"][r0:r1], f["q_sdf"][r0:r1]], 1), 1, take)
                     col, dep, acc, sdf = composite(P, rgba_f, o["z_fine"][r0:r1], msdf)
                     outs.update({"tex_fg_fine": col, "depth_fine": dep, "alpha_fine": acc, "sdf": sdf})
@@ -383,22 +393,43 @@ class PassGradient(torch.autograd.Function):
                 del outs, pairs, col, dep, acc
                 # (2) the per-sample networks, one block of samples after the other (samples are independent): only one block's graph exists at a
                 #     time, which is what bounds the step's memory -- the coarse and the fine batch are never alive together
-                for part, d_rgba in zip((c, f), grads[:len(per_sample)]):
-                    if d_rgba is None:
-                        continue
+                d_per = list(grads[:len(per_sample)])
+                # every sample of the chunk in one list: [coarse | new]; a second (noise, gradient) column exists when the coarse points appear
+                # in the fine composite with other draws (zeros for the new samples there)
+                parts = [(c, d_per[0], None if cf is None else (cf["noise"], d_per[2]))]
+                if f is not None:
+                    parts.append((f, d_per[1], None))
+                cols = {"pts": [], "q_sdf": [], "q_vis": [], "knn": [], "noise": [], "d": [], "noise2": [], "d2": []}
+                for part, d, second in parts:
                     S = part["pts"].shape[0] // R
-                    d_flat = d_rgba.reshape(-1, 5)
-                    n0, n1 = r0 * S, r1 * S
-                    block = spec.get("samples_per_block") or (n1 - n0)
-                    for b0 in range(n0, n1, block):
-                        sl = slice(b0, min(n1, b0 + block))
-                        noise = None if part["noise"] is None else part["noise"][sl]
-                        rgba = networks_at(P, dict(frame, table29=table), part["pts"][sl], part["q_sdf"].reshape(-1)[sl], part["q_vis"][sl],
-                                           part["knn"][sl].long(), noise, spec["sp_args"])
-                        g_block = torch.autograd.grad(rgba, loc + [table], d_flat[b0 - n0:b0 - n0 + rgba.shape[0]], allow_unused=True)
-                        del rgba
-                        accumulate(g_block[:-1])
-                        if g_block[-1] is not None:
-                            g_table += g_block[-1]
+                    sl = slice(r0 * S, r1 * S)
+                    n = sl.stop - sl.start
+                    cols["pts"].append(part["pts"][sl]); cols["q_sdf"].append(part["q_sdf"].reshape(-1)[sl]); cols["q_vis"].append(part["q_vis"][sl])
+                    cols["knn"].append(part["knn"][sl])
+                    cols["noise"].append(None if part["noise"] is None else part["noise"][sl])
+                    cols["d"].append(torch.zeros(n, 5, device=part["pts"].device) if d is None else d.reshape(-1, 5))
+                    if cf is not None:
+                        cols["noise2"].append(torch.zeros(n, device=part["pts"].device) if second is None else second[0][sl])
+                        cols["d2"].append(torch.zeros(n, 5, device=part["pts"].device) if second is None or second[1] is None else second[1].reshape(-1, 5))
+                cat = lambda k: torch.cat(cols[k], 0) if len(cols[k]) > 1 else cols[k][0]
+                pts_a, qs_a, qv_a, knn_a, d_a = cat("pts"), cat("q_sdf"), cat("q_vis"), cat("knn"), cat("d")
+                nz_a = None if cols["noise"][0] is None else cat("noise")
+                nz2_a, d2_a = (cat("noise2"), cat("d2")) if cf is not None else (None, None)
+                n_all = pts_a.shape[0]
+                block = spec.get("samples_per_block") or n_all
+                for b0 in range(0, n_all, block):
+                    sl = slice(b0, min(n_all, b0 + block))
+                    noise = None if nz_a is None else nz_a[sl]
+                    if nz2_a is not None:
+                        noise = (noise, nz2_a[sl])
+                    outs_b = networks_at(P, dict(frame, table29=table), pts_a[sl], qs_a[sl], qv_a[sl], knn_a[sl].long(), noise, spec["sp_args"])
+                    if nz2_a is not None:
+                        g_block = torch.autograd.grad(list(outs_b), loc + [table], [d_a[sl], d2_a[sl]], allow_unused=True)
+                    else:
+                        g_block = torch.autograd.grad(outs_b, loc + [table], d_a[sl], allow_unused=True)
+                    del outs_b
+                    accumulate(g_block[:-1])
+                    if g_block[-1] is not None:
+                        g_table += g_block[-1]
             accumulate(torch.autograd.grad(table_graph, loc, g_table, allow_unused=True))
         return (None, *total)
