@@ -308,9 +308,9 @@ def straight_through(value, graph):
 
 
 # Rays per chunk of the backward pass (PassGradient); None = the whole patch at once.  Chunking by rays repeats both stages per chunk; the block
-# size below bounds memory more cheaply (it only cuts the second stage).  Measured on the 64x64 patch at 64 + 64 samples (786 k samples,
-# tools/perf_train_step.py, one MI355X): whole patch 51 ms / 7.2 GiB; blocks of 262 144 samples 65 ms / 4.1 GiB; 131 072: 84 ms / 2.4 GiB;
-# 65 536: 107 ms / 1.6 GiB.  With 288 GB of HBM the default is speed; model config keys `grad_rays_per_chunk`, `grad_samples_per_block`.
+# size below bounds memory more cheaply (it only cuts the second stage).  Measured on the 64x64 patch at 64 + 64 samples (
+# tools/perf_train_step.py, one MI355X; 524 k network evaluations per step): whole patch 42 ms / 7.5 GiB; blocks of 262 144 samples 53 ms / 4.2 GiB;
+# 131 072: 63 ms / 2.5 GiB.  With 288 GB of HBM the default is speed; model config keys `grad_rays_per_chunk`, `grad_samples_per_block`.
 # (bf16 operands for this graph's GEMMs were measured too: 9 % faster, and the parameter gradients moved by 4e-2 relative -- dropped.)
 GRAD_RAYS_PER_CHUNK = None
 # Samples per block of the second stage of the backward pass (PassGradient); None = all samples of a chunk of rays in one block.
