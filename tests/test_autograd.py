@@ -199,3 +199,32 @@ def test_geometry_branch_on_valid_samples_only_gives_the_same_gradients():
     assert set(grads[0]) == set(grads[1]) and len(grads[0]) > 100
     for k in grads[0]:
         assert (grads[0][k] - grads[1][k]).norm() <= 3e-3 * grads[0][k].norm() + 1e-4, k
+
+
+def test_graphed_encoders_give_the_same_step():
+    """Config key `graph_encoders`: both image encoders as HIP graphs (forward and backward captured by torch.cuda.make_graphed_callables).
+    The training step must return the same images and leave the same gradients on every parameter, encoders included."""
+    import numpy as np
+    frame = synth.to_device(synth.make_frame(seed=3, tar_h=64, tar_w=64), "cuda")
+    res = []
+    for graphed in (False, True):
+        net = _net(0.01)
+        net.kwargs["graph_encoders"] = graphed
+        vals = []
+        for it in range(2):  # the second step replays the captured graphs
+            torch.manual_seed(3 + it)
+            np.random.seed(3 + it)
+            net.zero_grad(set_to_none=True)
+            out = _step(net, frame)
+            g = torch.Generator().manual_seed(1)
+            sum((out[k] * torch.randn(out[k].shape, generator=g).cuda()).sum() for k in KEYS).backward()
+            vals.append(({k: out[k].detach().clone() for k in KEYS}, {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}))
+        assert net._encoders_graphed == graphed
+        res.append(vals)
+    for it in range(2):
+        (out_a, grad_a), (out_b, grad_b) = res[0][it], res[1][it]
+        for k in KEYS:
+            assert (out_a[k] - out_b[k]).abs().max() <= 2e-4, (it, k)  # (MIOpen may pick other convolution solvers under capture)
+        assert set(grad_a) == set(grad_b) and any(k.startswith("geo_encoder.") for k in grad_a)
+        for k in grad_a:
+            assert (grad_a[k] - grad_b[k]).norm() <= 2e-2 * grad_a[k].norm() + 1e-4, (it, k)

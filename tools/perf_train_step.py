@@ -12,6 +12,8 @@ cfg = default_config()
 for key in ("grad_rays_per_chunk", "grad_samples_per_block"):  # e.g. --grad_samples_per_block 131072
     if "--" + key in sys.argv:
         cfg["models"]["VANeRF"][key] = int(sys.argv[sys.argv.index("--" + key) + 1])
+if "--graph_encoders" in sys.argv:  # the two image encoders as HIP graphs (forward and backward)
+    cfg["models"]["VANeRF"]["graph_encoders"] = True
 net = VANeRF(cfg).cuda().train()
 net.load_state_dict(synth.make_full_weights(0), strict=False)
 frame = synth.to_device(synth.make_frame(seed=3, tar_h=256, tar_w=256), "cuda")

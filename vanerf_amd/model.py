@@ -170,6 +170,7 @@ class VANeRF(nn.Module):
         self.precision = model_cfg.get("mfma_precision", "fp32")  # "fp32" | "bf16x3" (renderer.PRECISIONS); not a reference key
         self._packed = None  # (version key, PackedWeights)
         self._frame_cache = None
+        self._encoders_graphed = False
         self._enc_cache = None  # (key, feat_geo, feat_tex, image)
 
     @staticmethod
@@ -210,6 +211,27 @@ class VANeRF(nn.Module):
             return out
         self.attach_geo_feat(im, return_val)
         self.attach_tex_feat(im, return_val)
+
+    def _graph_encoders(self, im):
+        """Optional (config key `graph_encoders`): the two image encoders as HIP graphs, forward and backward (torch.cuda.make_graphed_callables).
+        Their ~800 small launches per training step cost the host more than the GPU (the step is host-bound while they are enqueued); as
+        graphs they cost two launches each.  Needs what graph capture needs: source images of one fixed shape, parameters that stay where
+        they are (in-place optimizer updates).  Same values and gradients (tests/test_autograd.py); eval-mode calls keep the eager path."""
+        def sample(ds):
+            x = im.view(-1, *im.shape[2:]) if len(im.shape) == 5 else im
+            for _ in range(ds):
+                x = thf.avg_pool2d(x, 2, stride=2)
+            return (2.0 * x - 1.0).detach().clone()
+
+        mods, args = [self.geo_encoder], [(sample(self.ds_geo),)]
+        if self.tex_encoder is not None:
+            mods.append(self.tex_encoder)
+            args.append((sample(self.ds_tex),))
+        graphed = torch.cuda.make_graphed_callables(tuple(mods), tuple(args), allow_unused_input=True)
+        self.geo_encoder = graphed[0]
+        if self.tex_encoder is not None:
+            self.tex_encoder = graphed[1]
+        self._encoders_graphed = True
 
     def attach_geo_feat(self, im, return_val=False):
         if not return_val:
@@ -483,6 +505,8 @@ class VANeRF(nn.Module):
         # come from the HIP pass, the gradients from vanerf_amd.torch_graph evaluated at the same samples (attach_autograd below).
         autograd = torch.is_grad_enabled() and self.training and any(p.requires_grad for p in self.parameters())
         dr_kwargs = self.kwargs.get("dr_kwargs", {})
+        if autograd and self.kwargs.get("graph_encoders") and not self._encoders_graphed and im.is_cuda:
+            self._graph_encoders(im)
         feat_geo = self.attach_geo_feat(im, return_val=True)
         feat_tex = self.attach_tex_feat(im, return_val=True)
         n_batch = im.shape[0] // n_views
