@@ -152,10 +152,12 @@ def test_chunked_backward_gives_the_same_gradients():
     whole patch (rays and samples are independent; the shared per-frame vertex table is closed once)."""
     frame = synth.to_device(synth.make_frame(seed=3, tar_h=64, tar_w=64), "cuda")
     grads = []
-    for chunk, block in ((None, None), (24, None), (None, 200), (40, 96)):  # 64 rays: one chunk / chunks of 24 + 24 + 16 rays / blocks of 200 samples / both
+    # 64 rays: one chunk / chunks of 24 + 24 + 16 rays / blocks of 200 samples / both / blocks of 300 samples as replays of one HIP graph
+    for chunk, block, graph in ((None, None, False), (24, None, False), (None, 200, False), (40, 96, False), (None, 300, True)):
         net = _net(0.01)
         net.kwargs["grad_rays_per_chunk"] = chunk
         net.kwargs["grad_samples_per_block"] = block
+        net.kwargs["grad_graph_blocks"] = graph
         torch.manual_seed(3)
         import numpy as np
         np.random.seed(3)

@@ -12,6 +12,8 @@ cfg = default_config()
 for key in ("grad_rays_per_chunk", "grad_samples_per_block"):  # e.g. --grad_samples_per_block 131072
     if "--" + key in sys.argv:
         cfg["models"]["VANeRF"][key] = int(sys.argv[sys.argv.index("--" + key) + 1])
+if "--grad_graph_blocks" in sys.argv:  # the blocks of the backward's second stage as replays of one HIP graph
+    cfg["models"]["VANeRF"]["grad_graph_blocks"] = True
 if "--graph_encoders" in sys.argv:  # the two image encoders as HIP graphs (forward and backward)
     cfg["models"]["VANeRF"]["graph_encoders"] = True
 net = VANeRF(cfg).cuda().train()

@@ -492,7 +492,8 @@ class VANeRF(nn.Module):
         keys = [k for k in ("tex_fg", "depth", "alpha", "tex_fg_fine", "depth_fine", "alpha_fine", "sdf") if k in out]
         spec = {"values": [out[k] for k in keys], "keys": keys, "names": names, "frame": frame, "pass": o, "sp_args": self.kwargs["sp_args"],
                 "rays_per_chunk": self.kwargs.get("grad_rays_per_chunk", G.GRAD_RAYS_PER_CHUNK),
-                "samples_per_block": self.kwargs.get("grad_samples_per_block", G.GRAD_SAMPLES_PER_BLOCK)}
+                "samples_per_block": self.kwargs.get("grad_samples_per_block", G.GRAD_SAMPLES_PER_BLOCK),
+                "graph_blocks": bool(self.kwargs.get("grad_graph_blocks", False))}
         for k, v in zip(keys, G.PassGradient.apply(spec, *leaves)):
             out[k] = v
         return out

@@ -149,6 +149,9 @@ def project_vertices(vert, cam):
     return torch.stack([2.0 * (xy[:, 0] / (cam["width"] - 1.0)) - 1.0, 2.0 * (xy[:, 1] / (cam["height"] - 1.0)) - 1.0], -1)
 
 
+_FREQ = {}
+
+
 def positional_encoding(pts, kpt3d, extrin, levels=3, scale=1.0, sigma=0.1):
     """SpatialEncoder 'rel_z_decay' (src/spatial.py:59-84, 109-117, 20-43): (N,3) -> (N, (1 + 2 levels) K), blocks [dz | sin.. | cos..] x w."""
     Rm, t = extrin[0, :3, :3], extrin[0, :3, 3]
@@ -157,7 +160,10 @@ def positional_encoding(pts, kpt3d, extrin, levels=3, scale=1.0, sigma=0.1):
     d = c[:, None] - k[None]                                          # (N,K,3)
     w = torch.exp(-(d ** 2).sum(-1) / (2.0 * sigma ** 2))             # (N,K)
     x = scale * d[..., 2]                                             # (N,K)
-    freq = torch.tensor([math.pi * 2 ** l for l in range(levels)], dtype=torch.float32, device=pts.device)
+    key = (levels, str(pts.device))
+    if key not in _FREQ:  # (built once: a host-to-device copy has no place inside a captured graph)
+        _FREQ[key] = torch.tensor([math.pi * 2 ** l for l in range(levels)], dtype=torch.float32, device=pts.device)
+    freq = _FREQ[key]
     y = x[:, None, :] * freq[None, :, None]                           # (N,L,K)
     blocks = torch.cat([x[:, None], torch.stack((torch.sin(y), torch.cos(y)), 2).reshape(x.shape[0], -1, x.shape[1])], 1)  # [x | sin l0 | cos l0 | sin l1 | ..]
     return (blocks * w[:, None]).reshape(pts.shape[0], -1)
@@ -320,6 +326,112 @@ GRAD_SAMPLES_PER_BLOCK = None
 COMPACT_VALID = True  # networks_at: evaluate the geometry branch on valid samples only (tests compare both settings)
 
 
+class _BlockGraph:
+    """Second stage of PassGradient for blocks of ONE fixed size, captured once as a HIP graph and replayed block after block (config key
+    `grad_graph_blocks`, with `grad_samples_per_block`).  Small blocks bound the step's memory, but eagerly every block re-launches the
+    graph's ~2 000 kernels and the step turns host-bound (131 072 samples per block: 63 ms); replayed, a block costs the host a few input
+    copies.  What capture needs: inputs, per-frame tensors and gradient accumulators at fixed addresses (copied in, read out), parameters that
+    stay where they are (in-place optimizer updates; a moved parameter re-captures), no data-dependent shapes (the valid-sample compaction of
+    networks_at is off inside: every sample of a block is evaluated)."""
+    cache = {}
+
+    def __init__(self, leaves, names, frame, table, block, two, with_noise, sp_args):
+        dev = table.device
+        f32 = torch.float32
+        self.block, self.two = block, two
+        self.pts, self.qs = torch.zeros(block, 3, device=dev), torch.zeros(block, device=dev)
+        self.qv, self.knn = torch.zeros(block, dtype=frame_dtype(frame, "q_vis"), device=dev), torch.zeros(block, dtype=torch.int32, device=dev)
+        self.nz = torch.zeros(block, device=dev) if with_noise else None
+        self.nz2 = torch.zeros(block, device=dev) if two else None
+        self.d, self.d2 = torch.zeros(block, 5, device=dev), (torch.zeros(block, 5, device=dev) if two else None)
+        # leaves: parameters are read where they live; the encoders' feature maps (new tensors every step) and the vertex table get fixed homes
+        self.static = {n: (t.detach().clone() if n.startswith("@") else t.detach()).requires_grad_(True) for n, t in zip(names, leaves)}
+        self.table = table.detach().clone().requires_grad_(True)
+        self.frame = {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in frame.items() if k not in ("cam", "feat_geo", "feat_tex", "table29")}
+        self.frame["cam"] = {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in frame["cam"].items()}
+        order = list(self.static.values()) + [self.table]
+        flat = torch.zeros(sum(t.numel() for t in order), dtype=f32, device=dev)
+        self.flat, self.acc, at = flat, [], 0
+        for t in order:
+            self.acc.append(flat[at:at + t.numel()].view(t.shape))
+            at += t.numel()
+        P = {k: v for k, v in self.static.items() if not k.startswith("@")}
+        fr = dict(self.frame, feat_geo=[self.static["@feat_geo0"], self.static["@feat_geo1"]], feat_tex=self.static["@feat_tex"], table29=self.table)
+
+        def body():
+            global COMPACT_VALID
+            keep, COMPACT_VALID = COMPACT_VALID, False
+            try:
+                noise = (self.nz, self.nz2) if two else self.nz
+                outs = networks_at(P, fr, self.pts, self.qs, self.qv, self.knn.long(), noise, sp_args)
+                grads = torch.autograd.grad(list(outs) if two else outs, order, [self.d, self.d2] if two else self.d, allow_unused=True)
+            finally:
+                COMPACT_VALID = keep
+            for a, g in zip(self.acc, grads):
+                if g is not None:
+                    a.add_(g)
+
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side), torch.enable_grad():
+            for _ in range(2):  # warm-up outside capture (library handles, workspaces, autotuning)
+                body()
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.enable_grad(), torch.cuda.graph(self.graph):
+            body()
+
+    def begin(self, leaves, names, frame, table):
+        """New step: this step's feature maps, per-frame tensors and vertex table into their fixed homes, accumulators to zero."""
+        with torch.no_grad():
+            for n, t in zip(names, leaves):
+                if n.startswith("@"):
+                    self.static[n].copy_(t)
+            self.table.copy_(table)
+            for k, v in self.frame.items():
+                if torch.is_tensor(v):
+                    v.copy_(frame[k])
+            for k, v in self.frame["cam"].items():
+                if torch.is_tensor(v):
+                    v.copy_(frame["cam"][k])
+            self.flat.zero_()
+
+    def run(self, pts, qs, qv, knn, nz, nz2, d, d2):
+        n = pts.shape[0]
+        with torch.no_grad():
+            for dst, src in ((self.pts, pts), (self.qs, qs), (self.qv, qv), (self.knn, knn), (self.nz, nz), (self.nz2, nz2), (self.d, d), (self.d2, d2)):
+                if dst is not None:
+                    dst[:n].copy_(src)
+            if n < self.block:  # the last, shorter block: the tail keeps old samples with zero output gradients -- they add nothing
+                self.d[n:].zero_()
+                if self.d2 is not None:
+                    self.d2[n:].zero_()
+        self.graph.replay()
+
+    def results(self):
+        out = self.flat.clone()
+        res, at = [], 0
+        for a in self.acc:
+            res.append(out[at:at + a.numel()].view(a.shape))
+            at += a.numel()
+        return res
+
+    @classmethod
+    def get(cls, leaves, names, frame, table, block, two, with_noise, sp_args):
+        cam = frame["cam"]
+        key = (block, two, with_noise, tuple(sorted(sp_args.items())), tuple(t.data_ptr() for n, t in zip(names, leaves) if not n.startswith("@")),
+               tuple(tuple(t.shape) for n, t in zip(names, leaves) if n.startswith("@")), tuple((k, float(v)) for k, v in sorted(cam.items()) if not torch.is_tensor(v)),
+               tuple((k, tuple(v.shape)) for k, v in sorted(frame.items()) if torch.is_tensor(v)), str(table.device))
+        if key not in cls.cache:
+            cls.cache.clear()  # one configuration at a time (each holds a block's activations in its private pool)
+            cls.cache[key] = cls(leaves, names, frame, table, block, two, with_noise, sp_args)
+        return cls.cache[key]
+
+
+def frame_dtype(frame, key):
+    return torch.uint8
+
+
 class PassGradient(torch.autograd.Function):
     """forward: the HIP pass's images, unchanged.  backward: the gradients of this module's graph at the samples of that pass with respect to
     the leaves (the module's parameters and the encoders' feature maps), in two stages: the composites are differentiated at the pass's own
@@ -417,6 +529,17 @@ class PassGradient(torch.autograd.Function):
                 nz2_a, d2_a = (cat("noise2"), cat("d2")) if cf is not None else (None, None)
                 n_all = pts_a.shape[0]
                 block = spec.get("samples_per_block") or n_all
+                if spec.get("graph_blocks") and spec.get("samples_per_block"):
+                    runner = _BlockGraph.get(list(ctx.saved_tensors), names, frame, table, block, nz2_a is not None, nz_a is not None, spec["sp_args"])
+                    runner.begin(list(ctx.saved_tensors), names, frame, table)
+                    for b0 in range(0, n_all, block):
+                        sl = slice(b0, min(n_all, b0 + block))
+                        runner.run(pts_a[sl], qs_a[sl], qv_a[sl], knn_a[sl], None if nz_a is None else nz_a[sl], None if nz2_a is None else nz2_a[sl],
+                                   d_a[sl], None if d2_a is None else d2_a[sl])
+                    res = runner.results()
+                    accumulate(res[:-1])
+                    g_table += res[-1]
+                    continue
                 for b0 in range(0, n_all, block):
                     sl = slice(b0, min(n_all, b0 + block))
                     noise = None if nz_a is None else nz_a[sl]
