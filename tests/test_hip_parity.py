@@ -141,6 +141,50 @@ def test_mesh_query_accel_on_other_meshes(R, rings, segs, G):
     assert 0.02 < (s0 < 0).float().mean() < 0.9
 
 
+@pytest.mark.parametrize("kind", ["flat_sheet", "one_triangle", "needle_fan", "duplicate_vertices"])
+def test_mesh_query_accel_on_degenerate_meshes(R, kind):
+    """Meshes the table builder and the searches must survive with the exhaustive scan's answers: an open flat sheet in a coordinate plane (zero
+    extent along one axis: a cell size of the (y,z) grid is the 1e-6 floor, cylinders without height), a single triangle (clusters padded with
+    the far-away dummies), a fan of needles around one vertex, and a sheet whose vertices all appear twice (coincident triangles: ties go to the
+    lowest face index)."""
+    g = torch.Generator().manual_seed(3)
+    if kind == "flat_sheet" or kind == "duplicate_vertices":
+        n = 12
+        gy, gz = torch.meshgrid(torch.linspace(-0.05, 0.05, n), torch.linspace(0.95, 1.05, n), indexing="ij")
+        verts = torch.stack([torch.full_like(gy, 0.01), gy, gz], -1).view(-1, 3)
+        idx = lambda i, j: i * n + j
+        faces = [(idx(i, j), idx(i + 1, j), idx(i, j + 1)) for i in range(n - 1) for j in range(n - 1)] + \
+                [(idx(i + 1, j), idx(i + 1, j + 1), idx(i, j + 1)) for i in range(n - 1) for j in range(n - 1)]
+        faces = torch.tensor(faces, dtype=torch.int32)
+        if kind == "duplicate_vertices":
+            faces = torch.cat([faces, faces + verts.shape[0]], 0)
+            verts = torch.cat([verts, verts], 0)
+    elif kind == "one_triangle":
+        verts = torch.tensor([[0.0, 0.0, 1.0], [0.05, 0.0, 1.0], [0.0, 0.05, 1.02]])
+        faces = torch.tensor([[0, 1, 2]], dtype=torch.int32)
+    else:  # needle_fan
+        k = 40
+        ang = torch.arange(k) * (2 * math.pi / k)
+        rim = torch.stack([0.08 * torch.cos(ang), 0.08 * torch.sin(ang), torch.full((k,), 1.0)], -1)
+        verts = torch.cat([torch.tensor([[0.0, 0.0, 1.0]]), rim, rim + torch.tensor([0.0, 0.0, 1e-4])], 0)
+        faces = torch.tensor([(0, 1 + i, 1 + k + i) for i in range(k)], dtype=torch.int32)
+    verts, faces = dev(verts.contiguous()), dev(faces.contiguous())
+    nv = verts.shape[0]
+    nx, ny, S = 16, 16, 9
+    pts = torch.cat([verts.cpu()[torch.randint(0, nv, (nx * ny * S - 500,), generator=g)] + 0.03 * torch.randn(nx * ny * S - 500, 3, generator=g),
+                     verts.cpu().mean(0) + 0.4 * torch.randn(500, 3, generator=g)], 0)
+    pts[:50] = verts.cpu()[torch.randint(0, nv, (50,), generator=g)]  # points exactly on vertices
+    pts = dev(pts.contiguous())
+    vv = dev((torch.rand(nv, generator=g) > 0.4).float())
+    accel = R.MeshAccel(verts, faces, grid=16)
+    s0, v0, f0 = R.mesh_query(verts, faces, vv, pts, want_face=True)
+    k0 = R.knn1(torch.cat([verts, torch.zeros(nv, 1, device="cuda")], 1).contiguous(), pts)
+    for grid in (None, (nx, ny, S)):
+        s1, v1, f1, k1 = R.mesh_query_accel(accel, verts, faces, vv, pts, want_face=True, grid=grid)
+        assert torch.equal(s0, s1) and torch.equal(v0, v1) and torch.equal(f0, f1) and torch.equal(k0, k1), (kind, grid)
+    assert torch.isfinite(s0).all()
+
+
 def test_mesh_accel_build_tables(R):
     """vanerf_mesh_accel_build (device-side builder, no host synchronisation): the tables it writes are what the searches assume --
     `orig` / the vertex table are permutations in Morton order, every triangle lies inside its sphere, its
