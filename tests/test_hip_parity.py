@@ -141,6 +141,31 @@ def test_mesh_query_accel_on_other_meshes(R, rings, segs, G):
     assert 0.02 < (s0 < 0).float().mean() < 0.9
 
 
+def test_mesh_query_accel_with_nonfinite_points(R):
+    """NaN / infinite sample positions (a degenerate camera upstream) must neither hang nor fault the searches, and the finite points that share
+    their 64-point tiles must keep their exact answers; the non-finite points get the exhaustive scan's (bit for bit, NaN included)."""
+    frame = _frame(3, 64)
+    verts = dev(frame["targets"]["vert_world"][0].contiguous())
+    faces = dev(frame["targets"]["face_world"][0].to(torch.int32))
+    nx, ny, S = 16, 16, 8
+    g = torch.Generator().manual_seed(2)
+    pts = _points_near_mesh(frame, nx * ny * S, seed=4)
+    bad = torch.randperm(pts.shape[0], generator=g)[:300]
+    pts[bad[:100]] = float("nan")
+    pts[bad[100:200], 0] = float("inf")
+    pts[bad[200:300], 2] = -float("inf")
+    pts = dev(pts.contiguous())
+    vv = dev((torch.rand(verts.shape[0], generator=g) > 0.5).float())
+    accel = R.MeshAccel(verts, faces)
+    s0, v0, f0 = R.mesh_query(verts, faces, vv, pts, want_face=True)
+    k0 = R.knn1(torch.cat([verts, torch.zeros(verts.shape[0], 1, device="cuda")], 1).contiguous(), pts)
+    bits = lambda t: t.view(torch.int32)
+    for grid in (None, (nx, ny, S)):
+        s1, v1, f1, k1 = R.mesh_query_accel(accel, verts, faces, vv, pts, want_face=True, grid=grid)
+        torch.cuda.synchronize()
+        assert torch.equal(bits(s0), bits(s1)) and torch.equal(v0, v1) and torch.equal(f0, f1) and torch.equal(k0, k1), grid
+
+
 @pytest.mark.parametrize("kind", ["flat_sheet", "one_triangle", "needle_fan", "duplicate_vertices"])
 def test_mesh_query_accel_on_degenerate_meshes(R, kind):
     """Meshes the table builder and the searches must survive with the exhaustive scan's answers: an open flat sheet in a coordinate plane (zero
