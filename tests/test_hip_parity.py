@@ -308,6 +308,10 @@ def test_mesh_query_tile_search_equals_brute_force(R, seed, hw, tar_w, orbit, S,
     rays = R.ray_setup(frame["cam_tar"], frame["bounds"], 0, 0, step, nx, ny, S, device="cuda")
     pts = R.sample_points(rays["rays_d"], rays["cam_pos"], rays["z"])
     g = torch.Generator().manual_seed(seed)
+    if seed == 11:  # a few hundred non-finite positions among the 2.9 M (the two-depth kernel variant must shrug them off like the one-depth one)
+        bad = torch.randint(0, pts.shape[0], (300,), generator=g).cuda()
+        pts[bad[:150]] = float("nan")
+        pts[bad[150:], 1] = float("inf")
     vv = dev((torch.rand(verts.shape[0], generator=g) > 0.5).float())
     accel = R.MeshAccel(verts, faces)
     s1, v1, f1, k1 = R.mesh_query_accel(accel, verts, faces, vv, pts, want_face=True, grid=(nx, ny, S))
@@ -316,10 +320,11 @@ def test_mesh_query_tile_search_equals_brute_force(R, seed, hw, tar_w, orbit, S,
     sub = pts[sel].contiguous()
     s0, v0, f0 = R.mesh_query(verts, faces, vv, sub, want_face=True)
     v4 = torch.cat([verts, torch.zeros(verts.shape[0], 1, device="cuda")], 1).contiguous()
-    assert torch.equal(s0, s1[sel]) and torch.equal(v0, v1[sel]) and torch.equal(f0, f1[sel]) and torch.equal(R.knn1(v4, sub), k1[sel])
+    bits = lambda t: t.view(torch.int32)  # (NaN distances compare by their bits)
+    assert torch.equal(bits(s0), bits(s1[sel].contiguous())) and torch.equal(v0, v1[sel]) and torch.equal(f0, f1[sel]) and torch.equal(R.knn1(v4, sub), k1[sel])
     # and the whole batch against the per-lane search (no hint)
     s2, v2, f2, k2 = R.mesh_query_accel(accel, verts, faces, vv, pts, want_face=True)
-    assert torch.equal(s1, s2) and torch.equal(v1, v2) and torch.equal(f1, f2) and torch.equal(k1, k2)
+    assert torch.equal(bits(s1), bits(s2)) and torch.equal(v1, v2) and torch.equal(f1, f2) and torch.equal(k1, k2)
     assert 0.001 < (s1 < 0).float().mean() < 0.9 and rays["hit"].float().mean() > 0.05
 
 

@@ -987,7 +987,9 @@ __global__ __launch_bounds__(MA_BLOCK) VANERF_MA_ATTR void mesh_query_accel_kern
         bool act;
         const long long i = locate(k, act);
         const float best = bestk[k];
-        const int bf = bfk[k] == 0x7fffffff ? 0 : bfk[k]; // NaN point (see above): never index the face table with the sentinel
+        // a point without a finite distance (NaN or infinite coordinates) answers face 0, as the exhaustive scan's strict `d < best` leaves it; the
+        // sentinel never indexes the face table
+        const int bf = (bfk[k] == 0x7fffffff || !(best < INFINITY)) ? 0 : bfk[k];
         // inside test on the (y,z) grid
         int cnt = 0;
         {
