@@ -81,6 +81,36 @@ def test_vertex_visibility_bit_exact(R):
         assert 0.2 < want.mean() < 0.8
 
 
+@pytest.mark.parametrize("case", ["spread", "behind_camera", "needles", "nonfinite", "tiny_raster"])
+def test_vertex_visibility_tiled_raster_equals_the_full_scan(R, case):
+    """The raster works on 16x16 pixel tiles and stages a face only where its box can reach (csrc/mesh_kernels.hip); the oracle scans every face for
+    every pixel.  Equal vertex flags on inputs that stress the staging rule: a mesh spread far beyond the raster, vertices behind the camera plane
+    (depth <= 0 after the (z + 1) / 2 map: the box rule does not apply to such faces), needle triangles, non-finite vertices, and a raster
+    that is not a multiple of the tile."""
+    frame = _frame(7, 64, 40.0)
+    xy01, z01 = orc.source_vert_xyz01(frame["targets"]["vert_world"], frame["cam_in"])
+    xy, z = xy01[0].clone(), z01[0].clone()
+    faces = frame["targets"]["face_world"][0].to(torch.int32)
+    g = torch.Generator().manual_seed(9)
+    size = 256
+    if case == "spread":
+        xy = (xy - 0.5) * 6.0 + 0.5
+    elif case == "behind_camera":
+        z[torch.randperm(z.shape[0], generator=g)[:200]] -= 3.0
+    elif case == "needles":
+        pick = torch.randperm(xy.shape[0], generator=g)[:150]
+        xy[pick] = xy[pick.roll(1)] + 1e-6 * torch.randn(150, 2, generator=g)
+    elif case == "nonfinite":
+        xy[torch.randperm(xy.shape[0], generator=g)[:20]] = float("nan")
+        z[torch.randperm(z.shape[0], generator=g)[:20]] = float("inf")
+    else:
+        size = 100
+    want = orc.vertex_visibility(xy, z, faces, size=size)[:, 0]
+    got = R.vertex_visibility(dev(xy.contiguous()), dev(z[:, 0].contiguous()), dev(faces), raster=size).cpu()
+    assert torch.equal(got, want), (case, int((got != want).sum()))
+    assert want.sum() > 0
+
+
 def test_mesh_query_bit_exact(R):
     frame = _frame(3, 64)
     p = _points_near_mesh(frame, 30000, seed=1)
