@@ -167,7 +167,9 @@ typedef struct {
                                 *           lies inside; second lower bound of the tile search of vanerf_mesh_query_accel (ray-grid hint) */
 } VanerfMeshAccel;
 
-/* Builds the tables above on the device, on `stream`, without a host synchronisation (seven small launches; 0.1 ms for the two-hand MANO mesh):
+/* Builds the tables above on the device, on `stream`, without a host synchronisation (seven small launches;
+ * no counterpart in the reference: kaolin's point_to_mesh_distance / check_sign behind cal_vis_sdf_batch, src/lib/dataset/mesh_util.py:498-524, and
+ * pytorch3d's knn_points, src/networks.py:28, scan all faces / vertices per point -- this is what lets vanerf_mesh_query_accel give their answers without; 0.1 ms for the two-hand MANO mesh):
  *     verts[NV][3], faces[NF][3] int32 (indices inside [0, NV): the caller's responsibility) -> *out, whose pointers point into `tables`,
  *     a caller-owned 16-byte-aligned device block of at least vanerf_mesh_accel_bytes(nv, nf, G, cell_capacity) bytes that must stay alive
  *     (and unmodified) for as long as *out is used.  G x G = cells of the (y,z) grid of the inside test (1..256; 64 for a hand mesh);
