@@ -222,7 +222,12 @@ def test_graphed_encoders_give_the_same_step():
             sum((out[k] * torch.randn(out[k].shape, generator=g).cuda()).sum() for k in KEYS).backward()
             vals.append(({k: out[k].detach().clone() for k in KEYS}, {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}))
         assert net._encoders_graphed == graphed
+        net.eval()  # eval-mode calls take the encoders' eager path (the graphs hold the training-mode computation)
+        with torch.no_grad():
+            vals.append([f.clone() for f in net.attach_geo_feat(frame["img_in"], return_val=True)] + [net.attach_tex_feat(frame["img_in"], return_val=True).clone()])
         res.append(vals)
+    for fa, fb in zip(res[0][2], res[1][2]):
+        assert (fa - fb).abs().max() <= 2e-3 * fa.abs().max(), "eval-mode feature maps after graphed training steps"
     for it in range(2):
         (out_a, grad_a), (out_b, grad_b) = res[0][it], res[1][it]
         for k in KEYS:
