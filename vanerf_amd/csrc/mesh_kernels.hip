@@ -283,7 +283,7 @@ constexpr int MA_MAX_CLUSTERS = 4096;
 constexpr int MA_MAX_VCLUSTERS = 1024;
 // tile searches (below): clusters a wave's candidate list can hold, and the 64-candidate rounds that makes
 #ifndef VANERF_TL_LIST
-#define VANERF_TL_LIST 128 // measured on the benchmark view: 64 -> 4.04 ms, 128 -> 3.46, 192 -> 4.43, 256 -> 4.18
+#define VANERF_TL_LIST 160 // measured on the benchmark view with the work queue: 64 -> 2.34 ms, 128 -> 2.00, 160 -> 1.93, 192 -> 1.95, 256 -> 2.16
 #endif
 constexpr int TL_LIST = VANERF_TL_LIST;
 constexpr int TL_IT = TL_LIST * CL / 64;
