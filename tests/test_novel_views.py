@@ -175,9 +175,10 @@ def test_orbit_on_hip_path_matches_per_frame_render():
     rgb, src = render_novel_views(net, cams, trb, only_renderings=True)
     assert rgb.shape == (4, 64, 64, 3) and src.shape == (1, 256, 256, 3)
     for i, cam in enumerate(cams):
-        out = net.render_pifu_nerf(None, net, trb["im"], trb["cam"], trb["hand_type"], trb["targets"], camera_to_cam_tar(cam), level=1,
-                                   sp_data=dict(trb["sp_data"]), fine=True, uniform=True, sample_per_ray_c=16, sample_per_ray_f=16,
-                                   src_foreground_mask=trb["src_foreground_mask"], bounds=trb["dr_data"]["bounds"], mask_at_box=None)
+        with torch.no_grad():  # as the orbit: the encoders' maps are kept (two MIOpen runs of the encoders are not bit-identical)
+            out = net.render_pifu_nerf(None, net, trb["im"], trb["cam"], trb["hand_type"], trb["targets"], camera_to_cam_tar(cam), level=1,
+                                       sp_data=dict(trb["sp_data"]), fine=True, uniform=True, sample_per_ray_c=16, sample_per_ray_f=16,
+                                       src_foreground_mask=trb["src_foreground_mask"], bounds=trb["dr_data"]["bounds"], mask_at_box=None)
         want = (out["tex_fg_fine"].clamp(0, 1).permute(1, 2, 0) * 255.0).to(torch.uint8).cpu().numpy()
         assert np.array_equal(rgb[i], want)
     assert rgb.std() > 0 and not np.array_equal(rgb[0], rgb[2])
@@ -252,8 +253,11 @@ def test_per_frame_caches_follow_their_inputs():
                                       sp_data=dict(trb["sp_data"]), fine=True, uniform=True, sample_per_ray_c=8, sample_per_ray_f=8,
                                       src_foreground_mask=trb["src_foreground_mask"], bounds=trb["dr_data"]["bounds"], mask_at_box=None)["tex_fg_fine"]
 
-    same = lambda x, y: (x - y).abs().max().item() <= 2e-4   # two networks: MIOpen may pick different convolution solvers
-    differs = lambda x, y: (x - y).abs().max().item() > 1e-3
+    # two networks = two MIOpen runs of the encoders, which are not bit-identical (feature maps differ by ~3e-7, tools/diag_orbit_state.py); once in a
+    # while that flips a discrete decision of a sample (DESIGN.md section 5 ii) and moves ONE pixel by ~3e-3: `same` bounds the fraction of
+    # elements above 2e-4 instead of the maximum, `differs` asks for a change all over the image
+    same = lambda x, y: ((x - y).abs() > 2e-4).float().mean().item() <= 0.01
+    differs = lambda x, y: ((x - y).abs() > 1e-3).float().mean().item() > 0.05
     net = fresh()
     enc_state = {k: v.clone() for k, v in net.state_dict().items() if k.startswith(("geo_encoder.", "tex_encoder."))}
     frame = synth.to_device(synth.make_frame(seed=3, tar_h=32, tar_w=32), "cuda")
@@ -367,9 +371,12 @@ def test_orbit_of_120_frames_as_config4_is_written(tmp_path):
     rgb_r, _ = render_novel_views(net, cams, trb, only_renderings=True, shard="rays")
     assert np.array_equal(rgb_r, rgb)
     for k in (0, 37, 119):
-        out = net.render_pifu_nerf(None, net, trb["im"], trb["cam"], trb["hand_type"], trb["targets"], camera_to_cam_tar(cams[k]), level=1,
-                                   sp_data=dict(trb["sp_data"]), fine=True, uniform=True, sample_per_ray_c=16, sample_per_ray_f=16,
-                                   src_foreground_mask=trb["src_foreground_mask"], bounds=trb["dr_data"]["bounds"], mask_at_box=None)
+        # under no_grad like the orbit itself: with autograd enabled VANeRF.encoded() re-runs both MIOpen encoders on every call, and two runs
+        # of them are not bit-identical (feature maps differ by ~3e-7, tools/diag_orbit_state.py), which flips a uint8 here and there
+        with torch.no_grad():
+            out = net.render_pifu_nerf(None, net, trb["im"], trb["cam"], trb["hand_type"], trb["targets"], camera_to_cam_tar(cams[k]), level=1,
+                                       sp_data=dict(trb["sp_data"]), fine=True, uniform=True, sample_per_ray_c=16, sample_per_ray_f=16,
+                                       src_foreground_mask=trb["src_foreground_mask"], bounds=trb["dr_data"]["bounds"], mask_at_box=None)
         want = (out["tex_fg_fine"].clamp(0, 1).permute(1, 2, 0) * 255.0).to(torch.uint8).cpu().numpy()
         assert np.array_equal(rgb[k], want), k
     seen = rgb.reshape(120, -1).astype(np.int16)

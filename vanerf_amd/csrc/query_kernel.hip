@@ -23,20 +23,26 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
 
-// Waves per SIMD of the split-bf16 kernel.  ONE, enforced by the register budget (__launch_bounds__(256, 1) gives the wave 512
-// registers, so a second wave cannot become resident): with two of these waves on a SIMD the kernel's results were not
-// reproducible run to run -- about 1e-3 of the 32-sample groups, always the last 16 lanes of the wave, first visible in
-// long-lived VGPRs (the gathered pixel features) -- while one wave per SIMD is bit-reproducible and matches the fp32-MFMA
-// kernel to 3.3e-5 on 10.9 M samples (tools/check_mode1_determinism.py).  The fp32-MFMA kernel never showed it at two waves.
-// Cause not isolated; the second wave was worth 5 % here, so it is not used.
+// Waves per SIMD of the split-bf16 kernel: TWO (round 3), as one 8-wave block per CU that owns the CU's LDS.  One in-order wave per SIMD
+// issues at most one instruction every ~4 cycles, and a full 32-sample group is ~9 700 instructions around 990 MFMAs: the wave was
+// issue-bound at ~54 k cycles per group with NO fragment traffic at all (timing experiment VANERF_EXP_FRAG_SRC=2), against 31.7 k cycles of
+// matrix-pipe time.  A second wave fills the issue slots; it needs the kernel in 256 registers WITHOUT scratch (build.py fails a build
+// that spills): key points in LDS instead of 63 VGPRs, gathers issued where they are used, fragment rings one k-step deep and kept per
+// output block, LDS addresses formed from three window bases (see LAddr).  Round 1 had tried two waves with the 476-register kernel cut
+// to 256 by the compiler (155 VGPRs in scratch): results were not reproducible run to run; the scratch-free
+// build is bit-identical to the one-wave build and reproducible (tools/check_mode1_determinism.py).  VANERF_WAVES_PER_SIMD_B=1
+// VANERF_WPB_B=4 builds the round-2 configuration (one 4-wave block per CU, 512 registers per wave).
 #ifndef VANERF_WAVES_PER_SIMD_B
-#define VANERF_WAVES_PER_SIMD_B 1
+#define VANERF_WAVES_PER_SIMD_B 2
 #endif
 #ifndef VANERF_WAVES_PER_SIMD
 #define VANERF_WAVES_PER_SIMD 2
 #endif
-constexpr int WAVES_PER_BLOCK = 4;
-constexpr int BLOCK = 64 * WAVES_PER_BLOCK;
+#ifndef VANERF_WPB_B
+#define VANERF_WPB_B (VANERF_WAVES_PER_SIMD_B == 2 ? 8 : 4)
+#endif
+// waves per block: the fp32 kernel runs two 4-wave blocks per CU, the split-bf16 kernel ONE block per CU (it owns the CU's LDS)
+template <int MODE> constexpr int WPB = MODE == 1 ? VANERF_WPB_B : 4;
 
 // Diagnostic build only (-DVANERF_STAMPS): per-phase s_memtime deltas summed per wave into QueryParams::stamps.
 // No stamp executes in the product build; stamp values never reach an output element.
@@ -181,19 +187,26 @@ __device__ __forceinline__ void run_layer(f32x16 (&acc)[NB], Ring<NB>& ring, WRs
 #ifndef VANERF_CHUNKS
 #define VANERF_CHUNKS 4
 #endif
-#ifndef VANERF_RINGB_WIDE
-#define VANERF_RINGB_WIDE 2
+// ring depth in BLOCK fragments (one (hi, lo) pair = 8 registers, 2 KB of stream) for layers with 4, 3, 2 and 1 output blocks.
+// One wave per SIMD: two k-steps ahead (4 for the one-block layers) cover the L2 latency (measured in steps, one session: (2,4,2) 8.16-8.23 ms,
+// (2,2,2) 8.24, (1,4,2) 8.25, (3,6,3) 8.32, (4,8,4) +4 %).  Two waves per SIMD: one step ahead -- the partner wave covers the rest and the ring
+// is what the 256-register budget cannot afford.
+#ifndef VANERF_DB4
+#define VANERF_DB4 (VANERF_WAVES_PER_SIMD_B == 2 ? 4 : 8)
 #endif
-#ifndef VANERF_RINGB_D1
-#define VANERF_RINGB_D1 4
+#ifndef VANERF_DB3
+#define VANERF_DB3 (VANERF_WAVES_PER_SIMD_B == 2 ? 3 : 6)
 #endif
-#ifndef VANERF_RINGB_D2
-#define VANERF_RINGB_D2 2
+#ifndef VANERF_DB2
+#define VANERF_DB2 (VANERF_WAVES_PER_SIMD_B == 2 ? 2 : 4)
+#endif
+#ifndef VANERF_DB1
+#define VANERF_DB1 (VANERF_WAVES_PER_SIMD_B == 2 ? 2 : 4)
 #endif
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
-template <int NB> struct WFragB { u32x4 hi[NB], lo[NB]; };
+struct FragB { u32x4 hi, lo; }; // A fragments (hi and lo parts) of one 32-row output block of one bf16 k-step
 
 // Fragments of the LAST layers of the stream stay resident in LDS for the whole launch (split-bf16 kernel: one block per CU, persistent):
 // every group needs them -- the all-invalid groups need nothing else -- and the CU's vector-memory path (L1: 64 B per clock) is what the
@@ -204,38 +217,76 @@ template <int NB> struct WFragB { u32x4 hi[NB], lo[NB]; };
 #endif
 constexpr int LDS_FIRST = VANERF_LDS_FIRST;
 constexpr unsigned RES_BASE_DW = layer_offset_b(LDS_FIRST), RES_DW = layer_offset_b(NUM_LAYERS) - layer_offset_b(LDS_FIRST);
-static_assert(RES_DW * 4u + 256u <= 160u * 1024u, "resident fragments + the block's small static LDS must fit the CU's 160 KB");
-extern __shared__ u32x4 s_wres[];
-template <int NB> struct RingDepthB { static constexpr int value = NB == 1 ? VANERF_RINGB_D1 : (NB == 2 ? VANERF_RINGB_D2 : VANERF_RINGB_WIDE); };
-template <int NB> struct RingB { WFragB<NB> f[RingDepthB<NB>::value]; };
-
-// step_dw: dword offset of (step, block 0, hi) in the stream; vb = lane * 16 bytes
-template <int NB, bool RES = false> __device__ __forceinline__ WFragB<NB> wload_b(WRsrc rs, unsigned step_dw, unsigned vb)
+// Two waves per SIMD (VANERF_WAVES_PER_SIMD_B == 2: 8-wave blocks, 256 registers per wave): nothing long-lived may sit in registers -- the
+// lane half's key points live in LDS behind the resident fragments (one ds_read_b128 per key point and group), gathers are issued right
+// before their use (the partner wave hides their latency), rings are one step deep.
+constexpr bool W2 = VANERF_WAVES_PER_SIMD_B == 2;
+// LDS map of the split-bf16 kernel (all of it in the dynamic region, which then starts at LDS address 0: no static __shared__ in this kernel):
+//   [0, 672)      the 42 key points as float4 (two-wave build)            [672, 768)  control words: s_base[2], s_valid[2][waves per block]
+//   [768, 768 + RES_DW * 4)  resident fragments
+constexpr unsigned LDS_KPT = 0u, LDS_CTRL = 2u * PE_KPT_PER_HALF * 16u, LDS_RES = 768u;
+constexpr unsigned DYN_LDS_BYTES = LDS_RES + RES_DW * 4u;
+static_assert(LDS_CTRL + 8u + 2u * 4u * VANERF_WPB_B <= LDS_RES, "control words overlap the resident fragments");
+static_assert(DYN_LDS_BYTES <= 160u * 1024u, "key points + control words + resident fragments must fit the CU's 160 KB");
+extern __shared__ __attribute__((aligned(16))) u32x4 s_dyn[];
+typedef __attribute__((address_space(3))) u32x4 lds_u32x4_t;
+typedef __attribute__((address_space(3))) unsigned lds_u32_t;
+// A ds instruction addresses base VGPR + 16-bit immediate.  Left to itself the compiler forms one base register (lane * 16 + constant) per
+// access beyond the first 64 KB, hoists all of them out of the sample loop and spills them; so the three 64 KB windows get one base each,
+// re-made opaque at the top of every round (LAddr), and every access names its window and its offset inside it.
+struct LAddr { unsigned w[3]; };
+__device__ __forceinline__ LAddr make_laddr(int lane)
 {
-    WFragB<NB> r;
+    LAddr a;
+    a.w[0] = (unsigned)lane * 16u;
+    asm volatile("" : "+v"(a.w[0]));
+    a.w[1] = a.w[0] + 0x10000u; a.w[2] = a.w[0] + 0x20000u;
+    asm volatile("" : "+v"(a.w[1]), "+v"(a.w[2]));
+    return a;
+}
+template <unsigned BYTE> __device__ __forceinline__ u32x4 lds_frag(const LAddr& a) // 16 bytes at LDS address BYTE + lane * 16
+{
+    return *reinterpret_cast<const lds_u32x4_t*>((size_t)(a.w[BYTE >> 16] + (BYTE & 0xffffu)));
+}
+__device__ __forceinline__ lds_u32_t* lds_ctrl() { return reinterpret_cast<lds_u32_t*>((size_t)LDS_CTRL); }
+template <int NB> struct RingDepthB { static constexpr int value = NB == 1 ? VANERF_DB1 : NB == 2 ? VANERF_DB2 : NB == 3 ? VANERF_DB3 : VANERF_DB4; };
+template <int NB> struct RingB { FragB b[RingDepthB<NB>::value]; };
+
+// DW: dword offset of the block's hi part in the stream (the lo part follows 1 KB later); the lane's 16 bytes sit at lane * 16
+template <bool RES, unsigned DW> __device__ __forceinline__ FragB wload_blk(WRsrc rs, const LAddr& la)
+{
+    FragB r;
     if constexpr (RES) { // resident layer: the same fragments from LDS
-#pragma unroll
-        for (int ob = 0; ob < NB; ++ob) {
-            r.hi[ob] = s_wres[(step_dw - RES_BASE_DW + (ob * 2 + 0) * 256) / 4 + (vb >> 4)];
-            r.lo[ob] = s_wres[(step_dw - RES_BASE_DW + (ob * 2 + 1) * 256) / 4 + (vb >> 4)];
-        }
+        r.hi = lds_frag<LDS_RES + (DW - RES_BASE_DW) * 4u>(la);
+        r.lo = lds_frag<LDS_RES + (DW - RES_BASE_DW + 256u) * 4u>(la);
         return r;
     }
-#pragma unroll
-    for (int ob = 0; ob < NB; ++ob) {
-        r.hi[ob] = __builtin_amdgcn_raw_buffer_load_b128(rs, vb, (step_dw + (ob * 2 + 0) * 256) * 4u, 0);
-        r.lo[ob] = __builtin_amdgcn_raw_buffer_load_b128(rs, vb, (step_dw + (ob * 2 + 1) * 256) * 4u, 0);
+#if defined(VANERF_EXP_FRAG_SRC) && VANERF_EXP_FRAG_SRC == 1 // timing experiment, wrong results: every fragment from LDS (wrapped into the resident region)
+    r.hi = lds_frag<LDS_RES + (DW % RES_DW) * 4u>(la);
+    r.lo = lds_frag<LDS_RES + ((DW + 256u) % RES_DW) * 4u>(la);
+    return r;
+#elif defined(VANERF_EXP_FRAG_SRC) && VANERF_EXP_FRAG_SRC == 2 // timing experiment, wrong results: no fragment traffic at all (stale registers)
+    {
+        const unsigned vb = la.w[0];
+        u32x4 a = {vb, vb + 1u, vb + 2u, vb + 3u}, b = {vb + 4u, vb + 5u, vb + 6u, vb + 7u};
+        asm volatile("" : "+v"(a), "+v"(b));
+        r.hi = a; r.lo = b;
+        return r;
     }
+#endif
+    r.hi = __builtin_amdgcn_raw_buffer_load_b128(rs, la.w[0], DW * 4u, 0);
+    r.lo = __builtin_amdgcn_raw_buffer_load_b128(rs, la.w[0], (DW + 256u) * 4u, 0);
     return r;
 }
 
-template <int NB, int T, bool RES = false> __device__ __forceinline__ RingB<NB> ring_start_b(WRsrc rs, unsigned sbase_dw, unsigned vb)
+// Block fragment i of a layer = (k-step i / NB, output block i % NB) lies i * 512 dwords into the layer's stream.
+template <int NB, int T, bool RES, unsigned SBASE_DW> __device__ __forceinline__ RingB<NB> ring_start_b(WRsrc rs, const LAddr& la)
 {
     constexpr int D = RingDepthB<NB>::value, S = (T + 7) / 8;
     RingB<NB> r;
     static_for<D>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
-        if constexpr (i < S) r.f[i] = wload_b<NB, RES>(rs, sbase_dw + i * NB * 512, vb);
+        if constexpr (i < S * NB) r.b[i] = wload_blk<RES, SBASE_DW + i * 512u>(rs, la);
     });
     __builtin_amdgcn_sched_barrier(0x000F); // keep the ring fill where it is written: ahead of the previous layer's epilogue
     return r;
@@ -259,8 +310,8 @@ struct NoPre { template <class C> __device__ __forceinline__ void operator()(C) 
 // So: step s's MFMAs are cut into four chunks, after each chunk comes one pair-split of step s+1's operands (5 VALU), the re-load of
 // the consumed ring slot is issued before the first chunk, and a sched_barrier(0) after every chunk keeps that order.
 // (sched_group_barrier could request the same interleave, but its solver did not finish on this 10 k-instruction block in 15 min.)
-template <int NB, int T, bool RES = false, int PRODS = 3, class Op, class Pre = NoPre>
-__device__ __forceinline__ void run_layer_b(f32x16 (&acc)[NB], RingB<NB>& ring, WRsrc rs, unsigned sbase_dw, unsigned vb, Op&& operand,
+template <int NB, int T, bool RES, unsigned SBASE_DW, int PRODS = 3, class Op, class Pre = NoPre>
+__device__ __forceinline__ void run_layer_b(f32x16 (&acc)[NB], RingB<NB>& ring, WRsrc rs, const LAddr& la, Op&& operand,
                                             Pre&& pre = Pre{})
 {
     constexpr int D = RingDepthB<NB>::value, S = (T + 7) / 8;
@@ -285,18 +336,24 @@ __device__ __forceinline__ void run_layer_b(f32x16 (&acc)[NB], RingB<NB>& ring, 
     __builtin_amdgcn_sched_barrier(0);
     static_for<S>([&](auto sc) {
         constexpr int s = decltype(sc)::value;
-        const WFragB<NB> a = ring.f[s % D];
-        if constexpr (s + D < S) ring.f[s % D] = wload_b<NB, RES>(rs, sbase_dw + (s + D) * NB * 512, vb);
+        FragB a[NB];
         const bf16x8 xh = __builtin_bit_cast(bf16x8, bh), xl = __builtin_bit_cast(bf16x8, bl);
         u32x4 nh = {}, nl = {};
-        // MFMA m of the step (m = 3*ob + product) belongs to chunk m * 4 / (3*NB); products of one block stay in order hh, hl, lh
+        // MFMA m of the step (m = 3*ob + product) belongs to chunk m * 4 / (3*NB); products of one block stay in order hh, hl, lh.
+        // A block's fragment leaves the ring at its first product and its slot is re-loaded at once with the fragment D blocks ahead.
         static_for<NCH>([&](auto cc) {
             constexpr int c = decltype(cc)::value;
             static_for<3 * NB>([&](auto mc) {
-                constexpr int m = decltype(mc)::value, ob = m / 3, pr = m % 3;
-                if constexpr (m * NCH / (3 * NB) == c && (pr == 0 || (pr == 1 && PRODS == 3) || (pr == 2 && PRODS >= 2))) {
-                    const bf16x8 wh = __builtin_bit_cast(bf16x8, a.hi[ob]), wl = __builtin_bit_cast(bf16x8, a.lo[ob]);
-                    acc[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pr == 2 ? wl : wh, pr == 1 ? xl : xh, acc[ob], 0, 0, 0);
+                constexpr int m = decltype(mc)::value, ob = m / 3, pr = m % 3, idx = s * NB + ob;
+                if constexpr (m * NCH / (3 * NB) == c) {
+                    if constexpr (pr == 0) {
+                        a[ob] = ring.b[idx % D];
+                        if constexpr (idx + D < S * NB) ring.b[idx % D] = wload_blk<RES, SBASE_DW + (idx + D) * 512u>(rs, la);
+                    }
+                    if constexpr (pr == 0 || (pr == 1 && PRODS == 3) || (pr == 2 && PRODS >= 2)) {
+                        const bf16x8 wh = __builtin_bit_cast(bf16x8, a[ob].hi), wl = __builtin_bit_cast(bf16x8, a[ob].lo);
+                        acc[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pr == 2 ? wl : wh, pr == 1 ? xl : xh, acc[ob], 0, 0, 0);
+                    }
                 }
             });
             if constexpr (s + 1 < S) {
@@ -313,17 +370,20 @@ __device__ __forceinline__ void run_layer_b(f32x16 (&acc)[NB], RingB<NB>& ring, 
 template <int MODE, int NB> struct RingSel { using type = Ring<NB>; };
 template <int NB> struct RingSel<1, NB> { using type = RingB<NB>; };
 
-template <int MODE, int NB, int T, int L> __device__ __forceinline__ typename RingSel<MODE, NB>::type ring_start_m(WRsrc rs, int lane)
+// `la`: the lane's place in a fragment -- its index (fp32 kernel) or its LDS / buffer byte offsets (split-bf16 kernel, LAddr)
+template <int MODE> struct LaneSel { using type = int; };
+template <> struct LaneSel<1> { using type = LAddr; };
+template <int MODE, int NB, int T, int L> __device__ __forceinline__ typename RingSel<MODE, NB>::type ring_start_m(WRsrc rs, const typename LaneSel<MODE>::type& la)
 {
-    if constexpr (MODE == 0) return ring_start<NB, T>(rs, layer_offset(L), (unsigned)lane * NB * 4u);
-    else return ring_start_b<NB, T, (L >= LDS_FIRST)>(rs, layer_offset_b(L), (unsigned)lane * 16u);
+    if constexpr (MODE == 0) return ring_start<NB, T>(rs, layer_offset(L), (unsigned)la * NB * 4u);
+    else return ring_start_b<NB, T, (L >= LDS_FIRST), layer_offset_b(L)>(rs, la);
 }
 
 template <int MODE, int NB, int T, int L, class Op>
-__device__ __forceinline__ void run_layer_m(f32x16 (&acc)[NB], typename RingSel<MODE, NB>::type& ring, WRsrc rs, int lane, Op&& operand)
+__device__ __forceinline__ void run_layer_m(f32x16 (&acc)[NB], typename RingSel<MODE, NB>::type& ring, WRsrc rs, const typename LaneSel<MODE>::type& la, Op&& operand)
 {
-    if constexpr (MODE == 0) run_layer<NB, T>(acc, ring, rs, layer_offset(L), (unsigned)lane * NB * 4u, static_cast<Op&&>(operand));
-    else run_layer_b<NB, T, (L >= LDS_FIRST), (((VANERF_P1_MASK >> L) & 1) ? 1 : ((VANERF_P2_MASK >> L) & 1) ? 2 : 3)>(acc, ring, rs, layer_offset_b(L), (unsigned)lane * 16u, static_cast<Op&&>(operand));
+    if constexpr (MODE == 0) run_layer<NB, T>(acc, ring, rs, layer_offset(L), (unsigned)la * NB * 4u, static_cast<Op&&>(operand));
+    else run_layer_b<NB, T, (L >= LDS_FIRST), layer_offset_b(L), (((VANERF_P1_MASK >> L) & 1) ? 1 : ((VANERF_P2_MASK >> L) & 1) ? 2 : 3)>(acc, ring, rs, la, static_cast<Op&&>(operand));
 }
 
 template <int NB> __device__ __forceinline__ void zero(f32x16 (&acc)[NB])
@@ -474,7 +534,7 @@ __device__ __forceinline__ Projected project_and_mask(const VanerfFrame& F, floa
 //   HC = channels per lane half (32 for the 64-channel map, 4 for the 8-channel map), NBO = output blocks,
 //   NREG_MID = registers of the last hidden block that carry real channels
 template <int MODE, int HC, int NBO, int NREG_MID, int l_at_a>
-__device__ __forceinline__ void geo_scale(WRsrc W, int lane, typename RingSel<MODE, 1>::type& ring_at,
+__device__ __forceinline__ void geo_scale(WRsrc W, int lane, const typename LaneSel<MODE>::type& la, typename RingSel<MODE, 1>::type& ring_at,
                                           float (&pix)[HC], float (&nn)[HC], float (&tw)[HC], float s0, float s1,
                                           f32x16 (&outacc)[NBO])
 {
@@ -490,13 +550,13 @@ __device__ __forceinline__ void geo_scale(WRsrc W, int lane, typename RingSel<MO
     };
     f32x16 at[1];
     zero<1>(at);
-    run_layer_m<MODE, 1, TIN, l_at_a>(at, ring_at, W, lane, input);
-    auto r_gate = ring_start_m<MODE, 1, 6, l_at_a + 1>(W, lane);
-    auto r_mid = ring_start_m<MODE, NBO, TIN, l_at_a + 2>(W, lane);
+    run_layer_m<MODE, 1, TIN, l_at_a>(at, ring_at, W, la, input);
+    auto r_gate = ring_start_m<MODE, 1, 6, l_at_a + 1>(W, la);
+    auto r_mid = ring_start_m<MODE, NBO, TIN, l_at_a + 2>(W, la);
     if constexpr (MODE == 0) relu<1>(at);
     f32x16 gate[1];
     zero<1>(gate);
-    run_layer_m<MODE, 1, 6, l_at_a + 1>(gate, r_gate, W, lane, [&](auto tc) -> float { return lazy_act<MODE, ACT_RELU>(at[0][decltype(tc)::value]); });
+    run_layer_m<MODE, 1, 6, l_at_a + 1>(gate, r_gate, W, la, [&](auto tc) -> float { return lazy_act<MODE, ACT_RELU>(at[0][decltype(tc)::value]); });
     // gates live in rows 0..2 = registers 0..2 of the h = 0 lanes
     const float a0 = __shfl(sigmoid_f(gate[0][0]), lane & 31);
     const float a1 = __shfl(sigmoid_f(gate[0][1]), lane & 31);
@@ -505,23 +565,29 @@ __device__ __forceinline__ void geo_scale(WRsrc W, int lane, typename RingSel<MO
     for (int t = 0; t < HC; ++t) { pix[t] *= a0; nn[t] *= a1; tw[t] *= a2; }
     f32x16 mid[NBO];
     zero<NBO>(mid);
-    run_layer_m<MODE, NBO, TIN, l_at_a + 2>(mid, r_mid, W, lane, input);
-    auto r_out = ring_start_m<MODE, NBO, TOUT, l_at_a + 3>(W, lane);
+    run_layer_m<MODE, NBO, TIN, l_at_a + 2>(mid, r_mid, W, la, input);
+    auto r_out = ring_start_m<MODE, NBO, TOUT, l_at_a + 3>(W, la);
     if constexpr (MODE == 0) relu<NBO>(mid);
     zero<NBO>(outacc);
-    run_layer_m<MODE, NBO, TOUT, l_at_a + 3>(outacc, r_out, W, lane,
+    run_layer_m<MODE, NBO, TOUT, l_at_a + 3>(outacc, r_out, W, la,
                          [&](auto tc) -> float { constexpr int t = decltype(tc)::value; return lazy_act<MODE, ACT_RELU>(mid[t / 16][t % 16]); });
 }
 
 template <int MODE>
-__global__ __launch_bounds__(BLOCK, MODE == 1 ? VANERF_WAVES_PER_SIMD_B : VANERF_WAVES_PER_SIMD) void query_kernel(const QueryParams P)
+__global__ __launch_bounds__(64 * WPB<MODE>, MODE == 1 ? VANERF_WAVES_PER_SIMD_B : VANERF_WAVES_PER_SIMD) void query_kernel(const QueryParams P)
 {
+    constexpr int WAVES_PER_BLOCK = WPB<MODE>, BLOCK = 64 * WAVES_PER_BLOCK;
 
     const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
     [[maybe_unused]] const long long wave = (long long)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6); // STAMPS builds
     const long long ngroups = (P.n + 31) / 32;
     const VanerfFrame& F = P.f;
-    const WRsrc W = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.w), 0, P.wbytes, 0x00020000); // kernarg-derived: wave-uniform
+#ifdef VANERF_EXP_SHARE_BOUND // timing experiment, wrong results: only wave 0 of a block fetches fragments (zero-record descriptor: the others' loads return 0 without traffic)
+    const unsigned wbytes_eff = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) == 0 ? P.wbytes : 0u;
+#else
+    const unsigned wbytes_eff = P.wbytes;
+#endif
+    const WRsrc W = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.w), 0, wbytes_eff, 0x00020000); // kernarg-derived: wave-uniform
     const float one_h0 = h ? 0.0f : 1.0f; // B operand of the bias k-step
 
 #ifdef VANERF_STAMPS
@@ -533,7 +599,9 @@ __global__ __launch_bounds__(BLOCK, MODE == 1 ? VANERF_WAVES_PER_SIMD_B : VANERF
     // split-bf16 kernel (one wave per SIMD, 512 registers): the lane half's 21 key points stay in registers for the whole launch
     // (63 VGPRs) -- per-group scalar loads of them exposed their latency 21 times per group with no second wave to hide it
     [[maybe_unused]] float kpx[PE_KPT_PER_HALF], kpy[PE_KPT_PER_HALF], kpz[PE_KPT_PER_HALF];
-    if constexpr (MODE == 1) {
+    if constexpr (MODE == 1 && W2) {
+        if (threadIdx.x < 2 * PE_KPT_PER_HALF) s_dyn[LDS_KPT / 16 + threadIdx.x] = reinterpret_cast<const u32x4*>(F.kpt_cam)[threadIdx.x];
+    } else if constexpr (MODE == 1) {
         const float4* __restrict__ kpl = reinterpret_cast<const float4*>(F.kpt_cam) + (h ? PE_KPT_PER_HALF : 0);
 #pragma unroll
         for (int i = 0; i < PE_KPT_PER_HALF; ++i) { const float4 k = kpl[i]; kpx[i] = k.x; kpy[i] = k.y; kpz[i] = k.z; }
@@ -557,22 +625,29 @@ __global__ __launch_bounds__(BLOCK, MODE == 1 ? VANERF_WAVES_PER_SIMD_B : VANERF
     // 660 KB from L2 on its own).  The claim for round r + 2 is issued at the start of round r (thread 0) and published through LDS at the
     // start of round r + 1: no wave waits for the atomic.  The same barrier makes the "no valid sample" decision block-uniform, which is what
     // allows barriers inside the layer stack.  Every block leaves the loop once the counter passes ngroups: the grid always drains.
-    __shared__ unsigned s_base[2];
-    __shared__ unsigned s_valid[2][WAVES_PER_BLOCK];
+    // control words in LDS: fp32 kernel static, split-bf16 kernel inside its dynamic region (see the LDS map above)
+    __shared__ unsigned s_ctrl0[MODE == 0 ? 2 + 2 * WAVES_PER_BLOCK : 1];
+    auto s_base = [&](unsigned i) -> auto& { if constexpr (MODE == 0) return s_ctrl0[i]; else return lds_ctrl()[i]; };
+    auto s_valid = [&](unsigned pp, unsigned k) -> auto& { if constexpr (MODE == 0) return s_ctrl0[2 + pp * WAVES_PER_BLOCK + k]; else return lds_ctrl()[2 + pp * WAVES_PER_BLOCK + k]; };
     const unsigned wv = threadIdx.x >> 6;
     unsigned pending = 0, par = 1;
-    if (threadIdx.x == 0) s_base[0] = atomicAdd(P.queue, (unsigned)WAVES_PER_BLOCK);
+    if (threadIdx.x == 0) s_base(0) = atomicAdd(P.queue, (unsigned)WAVES_PER_BLOCK);
     if constexpr (MODE == 1) { // resident fragments: one copy per block (the launch is persistent: 256 blocks x 156 KB from L2, once)
         const u32x4* __restrict__ src = reinterpret_cast<const u32x4*>(P.w) + RES_BASE_DW / 4;
-        for (unsigned i = threadIdx.x; i < RES_DW / 4; i += BLOCK) s_wres[i] = src[i];
+        for (unsigned i = threadIdx.x; i < RES_DW / 4; i += BLOCK) s_dyn[LDS_RES / 16 + i] = src[i];
     }
     __syncthreads();
-    unsigned base_cur = s_base[0];
+    unsigned base_cur = s_base(0);
     if (threadIdx.x == 0) pending = atomicAdd(P.queue, (unsigned)WAVES_PER_BLOCK);
     SampleIn in_next = fetch(base_cur + wv);
     while (base_cur < (unsigned)ngroups) {
         const long long g = (long long)base_cur + wv; // a wave whose group lies beyond the last one runs with live == false: the block's barriers stay matched
         const SampleIn in = in_next;
+        // the lane's fragment offsets, opaque per round (nothing derived from them is hoisted out of the loop and parked in registers)
+        typename LaneSel<MODE>::type la;
+        [[maybe_unused]] unsigned kp_lds = 0;
+        if constexpr (MODE == 1) { la = make_laddr(lane); kp_lds = LDS_KPT + ((la.w[0] >> 9) & 1u) * (PE_KPT_PER_HALF * 16u); }
+        else la = lane;
         const long long s_raw = g * 32 + j;
         const bool live = s_raw < P.n;
         long long s = live ? s_raw : P.n - 1;
@@ -585,11 +660,14 @@ __global__ __launch_bounds__(BLOCK, MODE == 1 ? VANERF_WAVES_PER_SIMD_B : VANERF
         const Projected pr = project_and_mask(F, P.wm1[0], P.hm1[0], px, py, pz);
         const float x = pr.x, y = pr.y, zn = pr.zn, mask = pr.mask;
         const bool wave_valid = __builtin_amdgcn_ballot_w64(mask > 0.0f) != 0ull;
-        if (lane == 0) s_valid[par][wv] = wave_valid ? 1u : 0u;
-        if (threadIdx.x == 0) s_base[par] = pending;
+        if (lane == 0) s_valid(par, wv) = wave_valid ? 1u : 0u;
+        if (threadIdx.x == 0) s_base(par) = pending;
         block_barrier_lds();
-        const unsigned base_next = (unsigned)__builtin_amdgcn_readfirstlane((int)s_base[par]);
-        const bool any_valid = __builtin_amdgcn_readfirstlane((int)(s_valid[par][0] | s_valid[par][1] | s_valid[par][2] | s_valid[par][3])) != 0;
+        const unsigned base_next = (unsigned)__builtin_amdgcn_readfirstlane((int)s_base(par));
+        unsigned anyv = 0;
+#pragma unroll
+        for (int k = 0; k < WAVES_PER_BLOCK; ++k) anyv |= s_valid(par, k);
+        const bool any_valid = __builtin_amdgcn_readfirstlane((int)anyv) != 0;
         par ^= 1u;
         if (threadIdx.x == 0) pending = atomicAdd(P.queue, (unsigned)WAVES_PER_BLOCK);
         in_next = fetch(base_next + wv);
@@ -645,7 +723,7 @@ __global__ __launch_bounds__(BLOCK, MODE == 1 ? VANERF_WAVES_PER_SIMD_B : VANERF
         // ibr_compress) survives.  When ALL 32 samples of the wave are such samples, GeoVisFusion, mlp_geo.layers1 and the head
         // (82 % of the MFMAs) are skipped -- same bits, wave-uniform branch.  With real foreground masks most samples are.
         if (any_valid) {
-            auto r_at0 = ring_start_m<MODE, 1, 98, L_GEO_AT0_A>(W, lane);
+            auto r_at0 = ring_start_m<MODE, 1, 98, L_GEO_AT0_A>(W, la);
             f32x16 g64[2], g8[1];
             float pix8[4], nn8[4], tw8[4];
             {
@@ -654,12 +732,16 @@ __global__ __launch_bounds__(BLOCK, MODE == 1 ? VANERF_WAVES_PER_SIMD_B : VANERF
                 gather<8>(F.geo0, b0, 64, 32 * h, pix);
                 load_row<8>(F.vfeat0, (unsigned)(nn_idx * 64 + 32 * h), nn);
                 load_row<8>(F.vfeat0, (unsigned)(tw_idx * 64 + 32 * h), tw);
-                const Bilin b1 = bilin_setup(x, y, F.h1, F.w1, P.wm1[3], P.hm1[3]);
-                gather<1>(F.geo1, b1, 8, 4 * h, pix8);
-                load_row<1>(F.vfeat1, (unsigned)(nn_idx * 8 + 4 * h), nn8);
-                load_row<1>(F.vfeat1, (unsigned)(tw_idx * 8 + 4 * h), tw8);
+                auto geo1_gathers = [&]() {
+                    const Bilin b1 = bilin_setup(x, y, F.h1, F.w1, P.wm1[3], P.hm1[3]);
+                    gather<1>(F.geo1, b1, 8, 4 * h, pix8);
+                    load_row<1>(F.vfeat1, (unsigned)(nn_idx * 8 + 4 * h), nn8);
+                    load_row<1>(F.vfeat1, (unsigned)(tw_idx * 8 + 4 * h), tw8);
+                };
+                if constexpr (!(MODE == 1 && W2)) geo1_gathers();
                 STAMP(2); // geo gathers
-                geo_scale<MODE, 32, 2, 16, L_GEO_AT0_A>(W, lane, r_at0, pix, nn, tw, sc0, sc1, g64);
+                geo_scale<MODE, 32, 2, 16, L_GEO_AT0_A>(W, lane, la, r_at0, pix, nn, tw, sc0, sc1, g64);
+                if constexpr (MODE == 1 && W2) geo1_gathers();
                 STAMP(3); // geo0 layers
             }
             // mlp0's ring (7 x dwordx4) starts before the small second scale runs
@@ -668,13 +750,14 @@ __global__ __launch_bounds__(BLOCK, MODE == 1 ? VANERF_WAVES_PER_SIMD_B : VANERF
             WFrag<4> ring0[D0];
             RingB<4> ring0b;
             {
-                auto r_at1 = ring_start_m<MODE, 1, 14, L_GEO_AT1_A>(W, lane);
+                auto r_at1 = ring_start_m<MODE, 1, 14, L_GEO_AT1_A>(W, la);
                 if constexpr (MODE == 0) {
                     static_for<D0>([&](auto fc) { constexpr int f = decltype(fc)::value; ring0[f] = wload<4>(W, (base0 + f * 256) * 4u, v4); });
-                } else {
-                    ring0b = ring_start_b<4, 180>(W, layer_offset_b(L_MLP0), (unsigned)lane * 16u);
+                } else if constexpr (!W2) {
+                    if constexpr (MODE == 1) ring0b = ring_start_b<4, 180, false, layer_offset_b(L_MLP0)>(W, la);
                 }
-                geo_scale<MODE, 4, 1, 4, L_GEO_AT1_A>(W, lane, r_at1, pix8, nn8, tw8, sc0, sc1, g8);
+                geo_scale<MODE, 4, 1, 4, L_GEO_AT1_A>(W, lane, la, r_at1, pix8, nn8, tw8, sc0, sc1, g8);
+                if constexpr (MODE == 1 && W2) ring0b = ring_start_b<4, 180, false, layer_offset_b(L_MLP0)>(W, la);
                 STAMP(4); // geo1
             }
 
@@ -697,7 +780,10 @@ __global__ __launch_bounds__(BLOCK, MODE == 1 ? VANERF_WAVES_PER_SIMD_B : VANERF
                     auto pe_features = [&](int i, float (&feat)[PE_FEATS]) {
                         // fp32 kernel: key points through the scalar cache (wave-uniform addresses), selected per lane half
                         float kx, ky, kz;
-                        if constexpr (MODE == 1) { kx = kpx[i]; ky = kpy[i]; kz = kpz[i]; }
+                        if constexpr (MODE == 1 && W2) {
+                            const u32x4 k = *reinterpret_cast<const lds_u32x4_t*>((size_t)(kp_lds + 16u * i));
+                            kx = __uint_as_float(k.x); ky = __uint_as_float(k.y); kz = __uint_as_float(k.z);
+                        } else if constexpr (MODE == 1) { kx = kpx[i]; ky = kpy[i]; kz = kpz[i]; }
                         else {
                             const float4 k0 = kpg[i], k1 = kpg[PE_KPT_PER_HALF + i];
                             kx = h ? k1.x : k0.x; ky = h ? k1.y : k0.y; kz = h ? k1.z : k0.z;
@@ -742,7 +828,7 @@ __global__ __launch_bounds__(BLOCK, MODE == 1 ? VANERF_WAVES_PER_SIMD_B : VANERF
                         // 179 the bias.  A bf16 step takes 8 consecutive pairs, so key point i is computed right before the first step
                         // that needs it (at most two key points are live at a time).
                         float feat[PE_KPT_PER_HALF][PE_FEATS];
-                        run_layer_b<4, 180, false, (((VANERF_P1_MASK >> L_MLP0) & 1) ? 1 : ((VANERF_P2_MASK >> L_MLP0) & 1) ? 2 : 3)>(a0, ring0b, W, layer_offset_b(L_MLP0), (unsigned)lane * 16u,
+                        run_layer_b<4, 180, false, layer_offset_b(L_MLP0), (((VANERF_P1_MASK >> L_MLP0) & 1) ? 1 : ((VANERF_P2_MASK >> L_MLP0) & 1) ? 2 : 3)>(a0, ring0b, W, la,
                             [&](auto tc) -> float {
                                 constexpr int t = decltype(tc)::value;
                                 if constexpr (t < 147) return feat[t / 7][t % 7];
@@ -759,29 +845,29 @@ __global__ __launch_bounds__(BLOCK, MODE == 1 ? VANERF_WAVES_PER_SIMD_B : VANERF
                     }
                 }
                 STAMP(5); // mlp0 (PE + geo64)
-                auto r1 = ring_start_m<MODE, 4, 65, L_MLP1>(W, lane);
+                auto r1 = ring_start_m<MODE, 4, 65, L_MLP1>(W, la);
                 if constexpr (MODE == 0) softplus<4>(a0);
                 f32x16 a1[4];
                 zero<4>(a1);
-                run_layer_m<MODE, 4, 65, L_MLP1>(a1, r1, W, lane, [&](auto tc) -> float { return chain_sp(a0, tc, std::integral_constant<int, 64>{}); });
-                auto r2 = ring_start_m<MODE, 4, 69, L_MLP2>(W, lane);
+                run_layer_m<MODE, 4, 65, L_MLP1>(a1, r1, W, la, [&](auto tc) -> float { return chain_sp(a0, tc, std::integral_constant<int, 64>{}); });
+                auto r2 = ring_start_m<MODE, 4, 69, L_MLP2>(W, la);
                 if constexpr (MODE == 0) softplus<4>(a1);
                 zero<4>(a0);
-                run_layer_m<MODE, 4, 69, L_MLP2>(a0, r2, W, lane, [&](auto tc) -> float {
+                run_layer_m<MODE, 4, 69, L_MLP2>(a0, r2, W, la, [&](auto tc) -> float {
                     constexpr int t = decltype(tc)::value;
                     if constexpr (t < 64) return lazy_act<MODE, ACT_SOFTPLUS>(a1[t / 16][t % 16]);
                     else if constexpr (t < 68) return g8[0][t - 64];
                     else return one_h0;
                 });
-                auto r3 = ring_start_m<MODE, 2, 61, L_MLP3>(W, lane);
+                auto r3 = ring_start_m<MODE, 2, 61, L_MLP3>(W, la);
                 if constexpr (MODE == 0) softplus<4>(a0);
                 zero<2>(xv);
-                run_layer_m<MODE, 2, 61, L_MLP3>(xv, r3, W, lane, [&](auto tc) -> float { return chain_sp(a0, tc, std::integral_constant<int, 60>{}); });
+                run_layer_m<MODE, 2, 61, L_MLP3>(xv, r3, W, la, [&](auto tc) -> float { return chain_sp(a0, tc, std::integral_constant<int, 60>{}); });
             }
             STAMP(6); // softplus x3 + mlp1..3
-            tex_gathers();
+            if constexpr (!(MODE == 1 && W2)) tex_gathers();
             // ---- PoolModule mean/var over V = 1 views (src/utils.py:744-779, 854-880) --------------------------
-            auto rh0 = ring_start_m<MODE, 2, 65, L_HEAD0>(W, lane);
+            auto rh0 = ring_start_m<MODE, 2, 65, L_HEAD0>(W, la);
     #pragma unroll
             for (int b = 0; b < 2; ++b)
     #pragma unroll
@@ -795,29 +881,30 @@ __global__ __launch_bounds__(BLOCK, MODE == 1 ? VANERF_WAVES_PER_SIMD_B : VANERF
             {
                 f32x16 m0[2], m1[2];
                 zero<2>(m0);
-                run_layer_m<MODE, 2, 65, L_HEAD0>(m0, rh0, W, lane, [&](auto tc) -> float { return chain(pool, tc, std::integral_constant<int, 64>{}); });
-                auto rh1 = ring_start_m<MODE, 2, 33, L_HEAD1>(W, lane);
+                run_layer_m<MODE, 2, 65, L_HEAD0>(m0, rh0, W, la, [&](auto tc) -> float { return chain(pool, tc, std::integral_constant<int, 64>{}); });
+                auto rh1 = ring_start_m<MODE, 2, 33, L_HEAD1>(W, la);
                 if constexpr (MODE == 0) softplus<2>(m0);
                 zero<2>(m1);
-                run_layer_m<MODE, 2, 33, L_HEAD1>(m1, rh1, W, lane, [&](auto tc) -> float { return chain_sp(m0, tc, std::integral_constant<int, 32>{}); });
-                auto rh2 = ring_start_m<MODE, 1, 33, L_HEAD2>(W, lane);
+                run_layer_m<MODE, 2, 33, L_HEAD1>(m1, rh1, W, la, [&](auto tc) -> float { return chain_sp(m0, tc, std::integral_constant<int, 32>{}); });
+                auto rh2 = ring_start_m<MODE, 1, 33, L_HEAD2>(W, la);
                 if constexpr (MODE == 0) softplus<2>(m1);
                 zero<1>(head);
-                run_layer_m<MODE, 1, 33, L_HEAD2>(head, rh2, W, lane, [&](auto tc) -> float { return chain_sp(m1, tc, std::integral_constant<int, 32>{}); });
+                run_layer_m<MODE, 1, 33, L_HEAD2>(head, rh2, W, la, [&](auto tc) -> float { return chain_sp(m1, tc, std::integral_constant<int, 32>{}); });
             }
         } else {
-            tex_gathers();
+            if constexpr (!(MODE == 1 && W2)) tex_gathers();
             zero<4>(pool);
             zero<1>(head);
         }
         if (!wave_valid && lane == 0 && g < ngroups) ++short_groups; // counted by the wave's own samples (what bench.py prices), not by the block's path
-        auto r_ibr = ring_start_m<MODE, 1, 65, L_IBR>(W, lane);
+        if constexpr (MODE == 1 && W2) tex_gathers();
+        auto r_ibr = ring_start_m<MODE, 1, 65, L_IBR>(W, la);
         STAMP(7); // pool + head
         // ---- ibr_compress_gfeat 128 -> 24 (src/model.py:921) ------------------------------------------------
-        auto r_ta = ring_start_m<MODE, 3, 49, L_TEX_AT_A>(W, lane);
+        auto r_ta = ring_start_m<MODE, 3, 49, L_TEX_AT_A>(W, la);
         f32x16 lat[1];
         zero<1>(lat);
-        run_layer_m<MODE, 1, 65, L_IBR>(lat, r_ibr, W, lane, [&](auto tc) -> float { return chain(pool, tc, std::integral_constant<int, 64>{}); });
+        run_layer_m<MODE, 1, 65, L_IBR>(lat, r_ibr, W, la, [&](auto tc) -> float { return chain(pool, tc, std::integral_constant<int, 64>{}); });
         STAMP(8); // ibr
         // ---- TexVisFusion per-sample part (src/networks.py:281-293) -----------------------------------------
         f32x16 rgb[1];
@@ -839,13 +926,13 @@ __global__ __launch_bounds__(BLOCK, MODE == 1 ? VANERF_WAVES_PER_SIMD_B : VANERF
             auto from_ta = [&](auto& ta_) { return [&](auto tc) -> float { constexpr int t = decltype(tc)::value; return lazy_act<MODE, ACT_RELU>(ta_[t / 16][t % 16]); }; };
             f32x16 ta[3];
             zero<3>(ta);
-            run_layer_m<MODE, 3, 49, L_TEX_AT_A>(ta, r_ta, W, lane, tex_in);
-            auto r_tg = ring_start_m<MODE, 1, 48, L_TEX_AT_B>(W, lane);
+            run_layer_m<MODE, 3, 49, L_TEX_AT_A>(ta, r_ta, W, la, tex_in);
+            auto r_tg = ring_start_m<MODE, 1, 48, L_TEX_AT_B>(W, la);
             if constexpr (MODE == 0) relu<3>(ta);
             f32x16 tg[1];
             zero<1>(tg);
-            run_layer_m<MODE, 1, 48, L_TEX_AT_B>(tg, r_tg, W, lane, from_ta(ta));
-            auto r_tb = ring_start_m<MODE, 3, 49, L_TEX_A>(W, lane);
+            run_layer_m<MODE, 1, 48, L_TEX_AT_B>(tg, r_tg, W, la, from_ta(ta));
+            auto r_tb = ring_start_m<MODE, 3, 49, L_TEX_A>(W, la);
             // six gates: rows 0..3 -> h = 0 lanes regs 0..3, rows 4,5 -> h = 1 lanes regs 0,1
             float m0 = sigmoid_f(tg[0][0]), m1 = sigmoid_f(tg[0][1]), m2 = sigmoid_f(tg[0][2]), m3 = sigmoid_f(tg[0][3]);
             float o0 = __shfl_xor(m0, 32), o1 = __shfl_xor(m1, 32), o2 = __shfl_xor(m2, 32);
@@ -862,11 +949,11 @@ __global__ __launch_bounds__(BLOCK, MODE == 1 ? VANERF_WAVES_PER_SIMD_B : VANERF
 #pragma unroll
             for (int r = 0; r < 12; ++r) latg[r] = lat[0][r] * glat;
             zero<3>(ta);
-            run_layer_m<MODE, 3, 49, L_TEX_A>(ta, r_tb, W, lane, tex_in);
-            auto r_rgb = ring_start_m<MODE, 1, 48, L_TEX_B>(W, lane);
+            run_layer_m<MODE, 3, 49, L_TEX_A>(ta, r_tb, W, la, tex_in);
+            auto r_rgb = ring_start_m<MODE, 1, 48, L_TEX_B>(W, la);
             if constexpr (MODE == 0) relu<3>(ta);
             zero<1>(rgb);
-            run_layer_m<MODE, 1, 48, L_TEX_B>(rgb, r_rgb, W, lane, from_ta(ta));
+            run_layer_m<MODE, 1, 48, L_TEX_B>(rgb, r_rgb, W, la, from_ta(ta));
         }
         STAMP(9); // tex
         // ---- eval_func (src/model.py:1140-1160): rows 0,1 of the head / 0..2 of the colour live in the h = 0 lanes ----
@@ -916,24 +1003,25 @@ extern "C" int vanerf_query_samples(const VanerfWeights* w, const VanerfFrame* f
           for (int i = 0; i < 4; ++i) { P.wm1[i] = (float)(ws[i] - 1); P.hm1[i] = (float)(hs[i] - 1); } }
        
         long long ngroups = (n + 31) / 32;
-        long long blocks = (ngroups + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
+        const int wpb = w->mode == 1 ? WPB<1> : WPB<0>;
+        long long blocks = (ngroups + wpb - 1) / wpb;
         int dev = 0, cus = 256;
         HIP_CHECK(hipGetDevice(&dev));
         HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
         // Two 4-wave blocks per CU = two waves per SIMD (256 VGPRs each).  fp32 MFMA and fp32 VALU do not overlap on gfx950
         // (tools/probe_mfma_valu.hip: every VALU instruction adds its issue cycles to the MFMA time), so the second wave does not
         // hide VALU work behind MFMAs; what it hides is load latency and the in-order issue gaps of its partner.
-        int per_cu = w->mode == 1 ? VANERF_WAVES_PER_SIMD_B : 2;
+        int per_cu = w->mode == 1 ? VANERF_WAVES_PER_SIMD_B * 4 / WPB<1> : 2;
         if (const char* e = getenv("VANERF_BLOCKS_PER_CU")) per_cu = atoi(e) > 0 ? atoi(e) : 2; // experiment knob
         long long cap = (long long)cus * per_cu;
         if (blocks > cap) blocks = cap;
         P.queue = w->queues + (w->next_queue.fetch_add(1u, std::memory_order_relaxed) % VanerfWeights::N_QUEUES);
         HIP_CHECK(hipMemsetAsync(P.queue, 0, sizeof(unsigned), (hipStream_t)stream));
         if (w->mode == 1) {
-            static const hipError_t lds_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(query_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(RES_DW * 4u));
-            HIP_CHECK(lds_ok);
-            hipLaunchKernelGGL(query_kernel<1>, dim3((unsigned)blocks), dim3(BLOCK), RES_DW * 4u, (hipStream_t)stream, P);
-        } else hipLaunchKernelGGL(query_kernel<0>, dim3((unsigned)blocks), dim3(BLOCK), 0, (hipStream_t)stream, P);
+            // the opt-in above 64 KB of dynamic LDS is per device: set on every call (cheap), as vanerf_mesh_query_accel does
+            HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(query_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DYN_LDS_BYTES));
+            hipLaunchKernelGGL(query_kernel<1>, dim3((unsigned)blocks), dim3(64 * WPB<1>), DYN_LDS_BYTES, (hipStream_t)stream, P);
+        } else hipLaunchKernelGGL(query_kernel<0>, dim3((unsigned)blocks), dim3(64 * WPB<0>), 0, (hipStream_t)stream, P);
         HIP_CHECK(hipGetLastError());
     });
 }
@@ -1042,15 +1130,17 @@ extern "C" int vanerf_debug_query_stamps(const VanerfWeights* w, const VanerfFra
         { const int ws[4] = {P.f.wi, P.f.wt, P.f.w0, P.f.w1}, hs[4] = {P.f.hi, P.f.ht, P.f.h0, P.f.h1};
           for (int i = 0; i < 4; ++i) { P.wm1[i] = (float)(ws[i] - 1); P.hm1[i] = (float)(hs[i] - 1); } }
         long long ngroups = (n + 31) / 32;
-        long long blocks = (ngroups + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
-        long long capd = w->mode == 1 ? 256LL * VANERF_WAVES_PER_SIMD_B : 512;
+        const int wpb = w->mode == 1 ? WPB<1> : WPB<0>;
+        long long blocks = (ngroups + wpb - 1) / wpb;
+        long long capd = w->mode == 1 ? 256LL * VANERF_WAVES_PER_SIMD_B * 4 / WPB<1> : 512;
         if (const char* e = getenv("VANERF_BLOCKS_PER_CU")) capd = 256LL * (atoi(e) > 0 ? atoi(e) : 2);
         if (blocks > capd) blocks = capd;
-        *n_waves = (int)blocks * WAVES_PER_BLOCK;
+        *n_waves = (int)blocks * wpb;
         P.queue = w->queues + (w->next_queue.fetch_add(1u, std::memory_order_relaxed) % VanerfWeights::N_QUEUES);
         HIP_CHECK(hipMemsetAsync(P.queue, 0, sizeof(unsigned), (hipStream_t)stream));
-        if (stamps && w->mode == 1) hipLaunchKernelGGL(query_kernel<1>, dim3((unsigned)blocks), dim3(BLOCK), RES_DW * 4u, (hipStream_t)stream, P);
-        else if (stamps) hipLaunchKernelGGL(query_kernel<0>, dim3((unsigned)blocks), dim3(BLOCK), 0, (hipStream_t)stream, P);
+        if (stamps && w->mode == 1) HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(query_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DYN_LDS_BYTES));
+        if (stamps && w->mode == 1) hipLaunchKernelGGL(query_kernel<1>, dim3((unsigned)blocks), dim3(64 * WPB<1>), DYN_LDS_BYTES, (hipStream_t)stream, P);
+        else if (stamps) hipLaunchKernelGGL(query_kernel<0>, dim3((unsigned)blocks), dim3(64 * WPB<0>), 0, (hipStream_t)stream, P);
         HIP_CHECK(hipGetLastError());
     });
 }
