@@ -188,20 +188,20 @@ __device__ __forceinline__ void run_layer(f32x16 (&acc)[NB], Ring<NB>& ring, WRs
 #define VANERF_CHUNKS 4
 #endif
 // ring depth in BLOCK fragments (one (hi, lo) pair = 8 registers, 2 KB of stream) for layers with 4, 3, 2 and 1 output blocks.
-// One wave per SIMD: two k-steps ahead (4 for the one-block layers) cover the L2 latency (measured in steps, one session: (2,4,2) 8.16-8.23 ms,
-// (2,2,2) 8.24, (1,4,2) 8.25, (3,6,3) 8.32, (4,8,4) +4 %).  Two waves per SIMD: one step ahead -- the partner wave covers the rest and the ring
-// is what the 256-register budget cannot afford.
+// One wave per SIMD, fragments from L2: two k-steps ahead (4 for the one-block layers) cover the latency (measured in steps, one session:
+// (2,4,2) 8.16-8.23 ms, (2,2,2) 8.24, (1,4,2) 8.25, (3,6,3) 8.32, (4,8,4) +4 %).  Two waves per SIMD, fragments from the LDS ring: two blocks
+// ahead (one for the one-block layers) -- 4 / 3 / 2 / 2 blocks measured the same 5.42 ms with 15 more registers, 6 / 4 spill.
 #ifndef VANERF_DB4
-#define VANERF_DB4 (VANERF_WAVES_PER_SIMD_B == 2 ? 4 : 8)
+#define VANERF_DB4 (VANERF_WAVES_PER_SIMD_B == 2 ? 2 : 8)
 #endif
 #ifndef VANERF_DB3
-#define VANERF_DB3 (VANERF_WAVES_PER_SIMD_B == 2 ? 3 : 6)
+#define VANERF_DB3 (VANERF_WAVES_PER_SIMD_B == 2 ? 2 : 6)
 #endif
 #ifndef VANERF_DB2
 #define VANERF_DB2 (VANERF_WAVES_PER_SIMD_B == 2 ? 2 : 4)
 #endif
 #ifndef VANERF_DB1
-#define VANERF_DB1 (VANERF_WAVES_PER_SIMD_B == 2 ? 2 : 4)
+#define VANERF_DB1 (VANERF_WAVES_PER_SIMD_B == 2 ? 1 : 4)
 #endif
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -212,8 +212,13 @@ struct FragB { u32x4 hi, lo; }; // A fragments (hi and lo parts) of one 32-row o
 // every group needs them -- the all-invalid groups need nothing else -- and the CU's vector-memory path (L1: 64 B per clock) is what the
 // fragment stream loads most (72 % of its cycles, profiles/r02_a_*): ds_read_b128 has four times that width and a fifth of the latency.
 // Layers VANERF_LDS_FIRST .. NUM_LAYERS-1 are copied once per block: head1, head2, ibr_compress and the four TexVisFusion layers = 156 KB.
+// Two-wave build: the layers in front of the resident ones are SHARED through an LDS ring (below), so only ibr_compress and the four
+// TexVisFusion layers (126 KB: what the all-invalid groups need) stay resident and 32 KB go to the ring.
+#ifndef VANERF_RING
+#define VANERF_RING (VANERF_WAVES_PER_SIMD_B == 2 ? 1 : 0)
+#endif
 #ifndef VANERF_LDS_FIRST
-#define VANERF_LDS_FIRST 13 /* L_HEAD1 */
+#define VANERF_LDS_FIRST (VANERF_RING ? 15 /* L_IBR */ : 13 /* L_HEAD1 */)
 #endif
 constexpr int LDS_FIRST = VANERF_LDS_FIRST;
 constexpr unsigned RES_BASE_DW = layer_offset_b(LDS_FIRST), RES_DW = layer_offset_b(NUM_LAYERS) - layer_offset_b(LDS_FIRST);
@@ -223,9 +228,16 @@ constexpr unsigned RES_BASE_DW = layer_offset_b(LDS_FIRST), RES_DW = layer_offse
 constexpr bool W2 = VANERF_WAVES_PER_SIMD_B == 2;
 // LDS map of the split-bf16 kernel (all of it in the dynamic region, which then starts at LDS address 0: no static __shared__ in this kernel):
 //   [0, 672)      the 42 key points as float4 (two-wave build)            [672, 768)  control words: s_base[2], s_valid[2][waves per block]
-//   [768, 768 + RES_DW * 4)  resident fragments
-constexpr unsigned LDS_KPT = 0u, LDS_CTRL = 2u * PE_KPT_PER_HALF * 16u, LDS_RES = 768u;
+//   [1024, 1024 + 32 KB)     fragment ring (two-wave build)               [LDS_RES, LDS_RES + RES_DW * 4)  resident fragments
+constexpr bool RING = VANERF_RING != 0;
+constexpr unsigned RING_PHASE_PIECES = 16u, RING_BYTES = RING ? 2u * RING_PHASE_PIECES * 1024u : 0u; // two halves of one 16 KB phase each
+constexpr unsigned LDS_KPT = 0u, LDS_CTRL = 2u * PE_KPT_PER_HALF * 16u, LDS_RING = 1024u, LDS_RES = RING ? LDS_RING + RING_BYTES : 768u;
 constexpr unsigned DYN_LDS_BYTES = LDS_RES + RES_DW * 4u;
+// The streamed part of the fragment stream (layers 0 .. LDS_FIRST-1) as 1 KB pieces (one (k-step, output block, hi | lo) fragment each = one
+// LDS-DMA wave instruction), in the order the layers consume them; a PHASE is 16 consecutive pieces.
+constexpr unsigned RING_PIECES = RES_BASE_DW / 256u, RING_PHASES = ((RING_PIECES + RING_PHASE_PIECES - 1u) / RING_PHASE_PIECES + 1u) / 2u * 2u;
+static_assert(!RING || VANERF_WPB_B == 8, "the ring's DMA schedule deals 2 pieces of a phase to each of 8 waves");
+static_assert(!RING || RING_PHASES * RING_PHASE_PIECES * 256u <= layer_offset_b(NUM_LAYERS), "the last phase's DMA must stay inside the stream");
 static_assert(LDS_CTRL + 8u + 2u * 4u * VANERF_WPB_B <= LDS_RES, "control words overlap the resident fragments");
 static_assert(DYN_LDS_BYTES <= 160u * 1024u, "key points + control words + resident fragments must fit the CU's 160 KB");
 extern __shared__ __attribute__((aligned(16))) u32x4 s_dyn[];
@@ -234,10 +246,14 @@ typedef __attribute__((address_space(3))) unsigned lds_u32_t;
 // A ds instruction addresses base VGPR + 16-bit immediate.  Left to itself the compiler forms one base register (lane * 16 + constant) per
 // access beyond the first 64 KB, hoists all of them out of the sample loop and spills them; so the three 64 KB windows get one base each,
 // re-made opaque at the top of every round (LAddr), and every access names its window and its offset inside it.
-struct LAddr { unsigned w[3]; };
-__device__ __forceinline__ LAddr make_laddr(int lane)
+struct LAddr {
+    unsigned w[3];
+    unsigned dma_lds, dma_src;  // (ring build) the wave's LDS-DMA destination / stream offset inside a phase, wave-uniform
+};
+__device__ __forceinline__ LAddr make_laddr(int lane, unsigned wv_uniform = 0u)
 {
     LAddr a;
+    a.dma_lds = LDS_RING + wv_uniform * 2048u; a.dma_src = wv_uniform * 2048u;
     a.w[0] = (unsigned)lane * 16u;
     asm volatile("" : "+v"(a.w[0]));
     a.w[1] = a.w[0] + 0x10000u; a.w[2] = a.w[0] + 0x20000u;
@@ -252,10 +268,70 @@ __device__ __forceinline__ lds_u32_t* lds_ctrl() { return reinterpret_cast<lds_u
 template <int NB> struct RingDepthB { static constexpr int value = NB == 1 ? VANERF_DB1 : NB == 2 ? VANERF_DB2 : NB == 3 ? VANERF_DB3 : VANERF_DB4; };
 template <int NB> struct RingB { FragB b[RingDepthB<NB>::value]; };
 
+// ---- the fragment ring (two-wave build) ---------------------------------------------------------------------------------------------
+// The eight waves of the block walk the same fragment stream one round at a time.  Fetched by every wave for itself, the stream is 8 x 516 KB
+// per round through the CU's 64 B / clock vector-memory path: 65 % busy, the largest share of what the waves wait for (profiles/r03_a_*).
+// Instead phase P (16 KB) is brought into one half of a 32 KB LDS ring ONCE -- every wave issues two `buffer_load_dwordx4 ... lds` (LDS-DMA:
+// 1 KB of memory to M0 + 16 * lane, no registers) -- while the waves read phase P - 1 from the other half with ds_read_b128.  Protocol, per
+// wave, at the first read of phase P (phase_begin<P>; everything is unrolled, so P is a compile-time constant at every read):
+//     s_waitcnt vmcnt(0) lgkmcnt(0)   my two pieces of phase P have landed (they were issued a phase ago); my reads of phase P - 1 are back
+//     s_barrier                        ... and so have / are everybody's: phase P may be read, the half of phase P - 1 may be overwritten
+//     issue the DMA of phase P + 1     into the half phase P - 1 occupied
+// The last phase issues phase 0 of the NEXT full round, the top-of-round barrier (every wave has passed a vmcnt(0) before its stores) stands in
+// for phase_begin<0>, and rounds that take the all-invalid path touch neither half: half 0 holds phase 0 whenever a round starts.
+// vmcnt(0) is exact here: in the two-wave build gathers are issued where they are consumed, nothing else is in flight inside the layer stack.
+template <unsigned P> __device__ __forceinline__ void ring_dma(WRsrc rs, const LAddr& la) // this wave's two pieces of phase P -> half P % 2
+{
+    constexpr unsigned lds_off = (P % 2u) * RING_PHASE_PIECES * 1024u, src_off = P * RING_PHASE_PIECES * 1024u;
+#if defined(VANERF_EXP_RING) && (VANERF_EXP_RING == 5 || VANERF_EXP_RING == 7)
+    unsigned soff5;
+    asm volatile("s_add_u32 m0, %1, %3\n\ts_add_u32 %0, %2, %4\n\ts_nop 0\n\t"
+                 "buffer_load_dwordx4 %5, %6, %0 offen lds\n\tbuffer_load_dwordx4 %5, %6, %0 offen offset:1024 lds"
+                 : "=&s"(soff5)
+                 : "s"(la.dma_lds), "s"(la.dma_src), "i"(lds_off), "i"(src_off), "v"(la.w[0]), "s"(rs)
+                 : "memory");
+    return;
+#endif
+    unsigned keep, soff;
+    // M0 = LDS destination (written and used in ONE statement: hipcc owns M0 everywhere else); one wait state between its write and the DMA
+    asm volatile("s_mov_b32 %0, m0\n\ts_add_u32 m0, %2, %4\n\ts_add_u32 %1, %3, %5\n\ts_nop 0\n\t"
+                 "buffer_load_dwordx4 %6, %7, %1 offen lds\n\tbuffer_load_dwordx4 %6, %7, %1 offen offset:1024 lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep), "=&s"(soff)
+                 : "s"(la.dma_lds), "s"(la.dma_src), "i"(lds_off), "i"(src_off), "v"(la.w[0]), "s"(rs)
+                 : "memory");
+}
+template <unsigned P> __device__ __forceinline__ void phase_begin(WRsrc rs, const LAddr& la)
+{
+#if defined(VANERF_EXP_RING) && VANERF_EXP_RING == 1 // timing experiments (results may be wrong): 1 no lgkmcnt wait, 2 no barrier, 3 no DMA, 4 nothing
+    if constexpr (P > 0) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    ring_dma<(P + 1u) % RING_PHASES>(rs, la);
+#elif defined(VANERF_EXP_RING) && VANERF_EXP_RING == 2
+    if constexpr (P > 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    ring_dma<(P + 1u) % RING_PHASES>(rs, la);
+#elif defined(VANERF_EXP_RING) && VANERF_EXP_RING == 3
+    if constexpr (P > 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#elif defined(VANERF_EXP_RING) && VANERF_EXP_RING == 4
+#elif defined(VANERF_EXP_RING) && VANERF_EXP_RING == 7
+    if constexpr (P > 0) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    ring_dma<(P + 1u) % RING_PHASES>(rs, la);
+#else
+    if constexpr (P > 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    ring_dma<(P + 1u) % RING_PHASES>(rs, la);
+#endif
+}
+
 // DW: dword offset of the block's hi part in the stream (the lo part follows 1 KB later); the lane's 16 bytes sit at lane * 16
 template <bool RES, unsigned DW> __device__ __forceinline__ FragB wload_blk(WRsrc rs, const LAddr& la)
 {
     FragB r;
+    if constexpr (RING && !RES) { // streamed layer, through the ring
+        constexpr unsigned q = DW / 256u; // piece index of the hi part
+        static_assert(q % 2u == 0 && q + 1u < RING_PHASES * RING_PHASE_PIECES, "block fragments are two consecutive pieces inside the streamed part");
+        if constexpr (q % RING_PHASE_PIECES == 0) phase_begin<q / RING_PHASE_PIECES>(rs, la);
+        r.hi = lds_frag<LDS_RING + (q % (2u * RING_PHASE_PIECES)) * 1024u>(la);
+        r.lo = lds_frag<LDS_RING + ((q + 1u) % (2u * RING_PHASE_PIECES)) * 1024u>(la);
+        return r;
+    }
     if constexpr (RES) { // resident layer: the same fragments from LDS
         r.hi = lds_frag<LDS_RES + (DW - RES_BASE_DW) * 4u>(la);
         r.lo = lds_frag<LDS_RES + (DW - RES_BASE_DW + 256u) * 4u>(la);
@@ -384,6 +460,14 @@ __device__ __forceinline__ void run_layer_m(f32x16 (&acc)[NB], typename RingSel<
 {
     if constexpr (MODE == 0) run_layer<NB, T>(acc, ring, rs, layer_offset(L), (unsigned)la * NB * 4u, static_cast<Op&&>(operand));
     else run_layer_b<NB, T, (L >= LDS_FIRST), layer_offset_b(L), (((VANERF_P1_MASK >> L) & 1) ? 1 : ((VANERF_P2_MASK >> L) & 1) ? 2 : 3)>(acc, ring, rs, la, static_cast<Op&&>(operand));
+}
+
+// lane id from v_mbcnt, not from a register that would have to stay live (or be spilled) across the whole sample loop
+__device__ __forceinline__ int lane_id_fresh()
+{
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
 }
 
 template <int NB> __device__ __forceinline__ void zero(f32x16 (&acc)[NB])
@@ -578,7 +662,8 @@ __global__ __launch_bounds__(64 * WPB<MODE>, MODE == 1 ? VANERF_WAVES_PER_SIMD_B
 {
     constexpr int WAVES_PER_BLOCK = WPB<MODE>, BLOCK = 64 * WAVES_PER_BLOCK;
 
-    const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
+    const int lane_k = threadIdx.x & 63;
+    [[maybe_unused]] const int lane = lane_k, j = lane & 31, h = lane >> 5; // (shadowed inside the sample loop)
     [[maybe_unused]] const long long wave = (long long)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6); // STAMPS builds
     const long long ngroups = (P.n + 31) / 32;
     const VanerfFrame& F = P.f;
@@ -588,7 +673,6 @@ __global__ __launch_bounds__(64 * WPB<MODE>, MODE == 1 ? VANERF_WAVES_PER_SIMD_B
     const unsigned wbytes_eff = P.wbytes;
 #endif
     const WRsrc W = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.w), 0, wbytes_eff, 0x00020000); // kernarg-derived: wave-uniform
-    const float one_h0 = h ? 0.0f : 1.0f; // B operand of the bias k-step
 
 #ifdef VANERF_STAMPS
     unsigned long long phase_cycles[N_PHASES] = {};
@@ -610,7 +694,7 @@ __global__ __launch_bounds__(64 * WPB<MODE>, MODE == 1 ? VANERF_WAVES_PER_SIMD_B
     // The six per-sample inputs of a group are fetched one group ahead (its index is known from the early claim): their HBM latency
     // is otherwise the first thing a group waits for, and a single wave per SIMD (bf16 kernel) has nobody to hide it.
     struct SampleIn { float px, py, pz, sdf; int knn; unsigned char vis; };
-    auto fetch = [&](unsigned grp) {
+    auto fetch = [&](unsigned grp, int j) {
         const long long sr = (long long)grp * 32 + j;
         long long sc = sr < P.n ? sr : P.n - 1; // also covers a claim beyond the last group (never used)
         if (P.order) sc = P.order[sc];
@@ -630,23 +714,33 @@ __global__ __launch_bounds__(64 * WPB<MODE>, MODE == 1 ? VANERF_WAVES_PER_SIMD_B
     auto s_base = [&](unsigned i) -> auto& { if constexpr (MODE == 0) return s_ctrl0[i]; else return lds_ctrl()[i]; };
     auto s_valid = [&](unsigned pp, unsigned k) -> auto& { if constexpr (MODE == 0) return s_ctrl0[2 + pp * WAVES_PER_BLOCK + k]; else return lds_ctrl()[2 + pp * WAVES_PER_BLOCK + k]; };
     const unsigned wv = threadIdx.x >> 6;
+    [[maybe_unused]] const unsigned wv_u = (unsigned)__builtin_amdgcn_readfirstlane((int)wv); // the same in a scalar register
     unsigned pending = 0, par = 1;
     if (threadIdx.x == 0) s_base(0) = atomicAdd(P.queue, (unsigned)WAVES_PER_BLOCK);
     if constexpr (MODE == 1) { // resident fragments: one copy per block (the launch is persistent: 256 blocks x 156 KB from L2, once)
         const u32x4* __restrict__ src = reinterpret_cast<const u32x4*>(P.w) + RES_BASE_DW / 4;
         for (unsigned i = threadIdx.x; i < RES_DW / 4; i += BLOCK) s_dyn[LDS_RES / 16 + i] = src[i];
+        if constexpr (RING) { // phase 0 of the ring, once: every full round re-issues it for its successor (see phase_begin)
+            const LAddr la0 = make_laddr(lane, wv_u);
+            ring_dma<0>(W, la0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
     }
     __syncthreads();
     unsigned base_cur = s_base(0);
     if (threadIdx.x == 0) pending = atomicAdd(P.queue, (unsigned)WAVES_PER_BLOCK);
-    SampleIn in_next = fetch(base_cur + wv);
+    SampleIn in_next = fetch(base_cur + wv, j);
     while (base_cur < (unsigned)ngroups) {
         const long long g = (long long)base_cur + wv; // a wave whose group lies beyond the last one runs with live == false: the block's barriers stay matched
         const SampleIn in = in_next;
+        // split-bf16 kernel: the lane id and what follows from it are re-derived in every round (v_mbcnt, volatile), so that none of it is carried
+        // around the loop in registers the 256-register budget does not have
+        const int lane = MODE == 1 ? lane_id_fresh() : lane_k, j = lane & 31, h = lane >> 5;
+        const float one_h0 = h ? 0.0f : 1.0f; // B operand of the bias k-step
         // the lane's fragment offsets, opaque per round (nothing derived from them is hoisted out of the loop and parked in registers)
         typename LaneSel<MODE>::type la;
         [[maybe_unused]] unsigned kp_lds = 0;
-        if constexpr (MODE == 1) { la = make_laddr(lane); kp_lds = LDS_KPT + ((la.w[0] >> 9) & 1u) * (PE_KPT_PER_HALF * 16u); }
+        if constexpr (MODE == 1) { la = make_laddr(lane, wv_u); kp_lds = LDS_KPT + ((la.w[0] >> 9) & 1u) * (PE_KPT_PER_HALF * 16u); }
         else la = lane;
         const long long s_raw = g * 32 + j;
         const bool live = s_raw < P.n;
@@ -670,7 +764,7 @@ __global__ __launch_bounds__(64 * WPB<MODE>, MODE == 1 ? VANERF_WAVES_PER_SIMD_B
         const bool any_valid = __builtin_amdgcn_readfirstlane((int)anyv) != 0;
         par ^= 1u;
         if (threadIdx.x == 0) pending = atomicAdd(P.queue, (unsigned)WAVES_PER_BLOCK);
-        in_next = fetch(base_next + wv);
+        in_next = fetch(base_next + wv, j);
         base_cur = base_next;
         __builtin_amdgcn_sched_barrier(0x000F); // keep these loads here (the scheduler sinks loads to their first use)
         const Bilin bi = bilin_setup(x, y, F.hi, F.wi, P.wm1[0], P.hm1[0]); // source-image taps (the same the mask used)
@@ -957,6 +1051,9 @@ __global__ __launch_bounds__(64 * WPB<MODE>, MODE == 1 ? VANERF_WAVES_PER_SIMD_B
         }
         STAMP(9); // tex
         // ---- eval_func (src/model.py:1140-1160): rows 0,1 of the head / 0..2 of the colour live in the h = 0 lanes ----
+        // ring build: the DMA this wave issued in the round's last phase (phase 0 of the next full round) has landed before the wave reaches
+        // the next top-of-round barrier -- waited for here, ahead of the stores, where nothing younger is in flight
+        if constexpr (MODE == 1 && RING) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (live && h == 0) {
             float rad = head[0][1];
             if (P.noise) rad += P.noise[s];
@@ -970,7 +1067,7 @@ __global__ __launch_bounds__(64 * WPB<MODE>, MODE == 1 ? VANERF_WAVES_PER_SIMD_B
         }
         STAMP(10); // store
     }
-    if (P.short_groups && lane == 0 && short_groups) atomicAdd(P.short_groups, (unsigned long long)short_groups);
+    if (P.short_groups && (MODE == 1 ? lane_id_fresh() : lane) == 0 && short_groups) atomicAdd(P.short_groups, (unsigned long long)short_groups);
 #ifdef VANERF_STAMPS
     unsigned long long rt1;
     asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt1)::"memory");
