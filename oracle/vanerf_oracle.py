@@ -341,11 +341,19 @@ def ray_bbox_intersection(bounds, orig, direct, boffset=(-0.01, 0.01)):
 # --------------------------------------------------------------------------------------------
 # per-sample query (src/model.py:748-957) and the whole pass (src/model.py:1102-1422)
 # --------------------------------------------------------------------------------------------
+def apply_transf(xy, cam):
+    """The optional 2-D affine behind the projection, cam['transf'] (B,2,3) (src/model.py:783-785, 848-850, 979-981, 1249-1251, 1261-1263)."""
+    if "transf" in cam:
+        t = cam["transf"]
+        xy = xy @ t[:, :2, :2].transpose(1, 2) + t[:, :, 2][:, None]
+    return xy
+
+
 def project(pts, cam):
     """src/model.py:780-788: (B,N,3) -> xy in [-1,1] (B,N,2), z in [-1,1] (B,N,1)."""
     vh = pts @ cam["KRT"][:, :3, :3].transpose(1, 2) + cam["KRT"][:, :3, 3][:, None]
     z = vh[..., 2:3]
-    xy = vh[..., :2] / z
+    xy = apply_transf(vh[..., :2] / z, cam)
     xy = torch.stack([2.0 * (xy[..., 0] / (cam["width"] - 1.0)) - 1.0, 2.0 * (xy[..., 1] / (cam["height"] - 1.0)) - 1.0], -1)
     z = 2.0 * (z - cam["znear"]) / (cam["zfar"] - cam["znear"]) - 1.0
     return xy, z
@@ -355,7 +363,7 @@ def project_verts(vert, cam):
     """src/model.py:845-853: vertices -> [-1,1] image coordinates (z + 1e-8 in the divide)."""
     vh = vert @ cam["KRT"][:, :3, :3].transpose(1, 2) + cam["KRT"][:, :3, 3][:, None]
     z = vh[..., 2:3]
-    xy = vh[..., :2] / (z + 1e-8)
+    xy = apply_transf(vh[..., :2] / (z + 1e-8), cam)
     return torch.stack([2.0 * (xy[..., 0] / (cam["width"] - 1.0)) - 1.0, 2.0 * (xy[..., 1] / (cam["height"] - 1.0)) - 1.0], -1)
 
 
@@ -487,7 +495,7 @@ def source_vert_xyz01(vert3d, cam):
     """src/model.py:1245-1255: source-view vertex coordinates fed to the visibility rasteriser."""
     vh = vert3d @ cam["KRT"][:, :3, :3].transpose(1, 2) + cam["KRT"][:, :3, 3][:, None]
     vz = vh[..., 2:3]
-    xy = vh[..., :2] / (vz + 1e-8)
+    xy = apply_transf(vh[..., :2] / (vz + 1e-8), cam)
     xy = torch.stack([xy[..., 0] / (cam["width"] - 1.0), xy[..., 1] / (cam["height"] - 1.0)], -1)
     vz = (vz - cam["znear"]) / (cam["zfar"] - cam["znear"])
     return xy, vz

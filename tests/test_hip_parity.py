@@ -792,12 +792,17 @@ def test_config1_128x128_32_samples(R, sd_full, precision):
 # ---------------------------------------------------------------------------------------------------------------------
 # the reference-shaped interface (vanerf_amd.model.VANeRF) on the GPU, against the fixtures captured from the reference
 # ---------------------------------------------------------------------------------------------------------------------
-@pytest.fixture(scope="module")
-def net(R, sd_full):
+@pytest.fixture(scope="module", params=["bf16x3", "fp32"])
+def net(R, sd_full, request):
+    """The drop-in module in BOTH arithmetic modes of the per-sample kernel (config key mfma_precision; bf16x3 is the default and the mode every
+    published number is measured in)."""
     from vanerf_amd.config import default_config
     from vanerf_amd.model import VANeRF
     torch.manual_seed(0)
-    m = VANeRF(default_config()).cuda().eval()
+    cfg = default_config()
+    cfg["models"]["VANeRF"]["mfma_precision"] = request.param
+    m = VANeRF(cfg).cuda().eval()
+    assert m.precision == request.param and VANeRF(default_config()).precision == "bf16x3"
     missing = m.load_state_dict(sd_full, strict=False)  # encoders keep their init: the fixtures pass feature maps explicitly
     assert not missing.unexpected_keys and all(k.startswith(("geo_encoder.", "tex_encoder.", "sp_encoder")) for k in missing.missing_keys)
     return m
@@ -844,9 +849,10 @@ def test_model_batch_render_vs_reference_golden(net, golden, tag, seed, hw, orbi
     out = net.batch_render_pifu_nerf(net, f["img_in"], f["cam_in"], f["hand_type"], f["targets"], 1, f["cam_tar"], level, strd, None, f["feat_geo"],
                                      f["feat_tex"], None, dict(f["sp_data"]), None, fine=True, uniform=True, sample_per_ray_c=S, sample_per_ray_f=S,
                                      src_foreground_mask=f["src_foreground_mask"], bounds=f["bounds"], mask_at_box=None)
+    outliers = OUTLIERS if net.precision == "fp32" else 2 * OUTLIERS  # as in test_render_pass_vs_reference_golden: 2 of the 256 pixels of the 16x16 case
     for k in ("tex_fg", "depth", "alpha", "tex_fg_fine", "depth_fine", "alpha_fine", "sdf"):
         assert out[k].shape == g[k].shape, k
-        assert_close_frac(out[k].cpu(), g[k], TOL, OUTLIERS, k)
+        assert_close_frac(out[k].cpu(), g[k], TOL, outliers, k)
     assert torch.equal(out["vert_vis"].cpu(), g["vert_vis"])
     for k in ("vis_img_all", "vis_img", "input_mask", "img_in"):
         assert k in out
@@ -865,10 +871,38 @@ def test_model_render_full_vs_reference_golden(net, golden):
                                    bounds=f["bounds"], mask_at_box=None)
     finally:
         del net.attach_geo_feat, net.attach_tex_feat
+    # 256 pixels: the allowance is two of them (besides the decisions named at OUTLIERS, importance sampling replaces a cdf step below 1e-5 by 1,
+    # src/model.py:1460 -- a 1e-5 difference of a coarse weight, which is what the two arithmetic modes differ by, moves that fine sample across its bin)
     for k in ("tex_fg", "tex_fg_fine", "depth_fine", "alpha_fine", "sdf"):
         assert ret[k].shape == g[k].shape, (k, ret[k].shape, g[k].shape)
-        assert_close_frac(ret[k].cpu(), g[k], TOL, OUTLIERS, k)
+        assert_close_frac(ret[k].cpu(), g[k], TOL, 2.0 / 256.0, k)
     assert (ret["vert_xy"].cpu() - g["vert_xy"]).abs().max() <= 1e-3  # pixel units (values ~1e2)
+
+
+def test_model_cam_transf_is_folded_into_the_projection(net, sd_full):
+    """cam_in['transf'] (src/model.py:783-785, 848-850, 1249-1251): the module folds the 2-D affine into KRT (VANeRF.fold_transf); the oracle applies
+    it behind the projection as the reference writes it.  Whole pass on 16x16 rays, 16 + 16 samples."""
+    from oracle import vanerf_oracle as orc
+    frame_cpu = synth.make_frame(seed=3, tar_h=16, tar_w=16)
+    transf = torch.tensor([[[0.97, 0.02, 3.0], [-0.015, 1.03, -2.0]]])
+    frame_cpu["cam_in"] = dict(frame_cpu["cam_in"], transf=transf)
+    f = synth.to_device(frame_cpu, "cuda")
+    assert "transf" in f["cam_in"]
+    S = 16
+    ref = orc.batch_render(sd_full, frame_cpu, 1, torch.tensor([[[0, 0]]]), S, S)
+    plain = orc.batch_render(sd_full, dict(frame_cpu, cam_in={k: v for k, v in frame_cpu["cam_in"].items() if k != "transf"}), 1,
+                             torch.tensor([[[0, 0]]]), S, S)
+    assert (ref["tex_fg_fine"] - plain["tex_fg_fine"]).abs().max() > 1e-2  # the affine matters
+    out = net.batch_render_pifu_nerf(net, f["img_in"], f["cam_in"], f["hand_type"], f["targets"], 1, f["cam_tar"], 1, 0, None, f["feat_geo"],
+                                     f["feat_tex"], None, dict(f["sp_data"]), None, fine=True, uniform=True, sample_per_ray_c=S, sample_per_ray_f=S,
+                                     src_foreground_mask=f["src_foreground_mask"], bounds=f["bounds"], mask_at_box=None)
+    for k in ("tex_fg", "depth", "alpha", "tex_fg_fine", "depth_fine", "alpha_fine"):
+        assert out[k].shape == ref[k].shape, k
+        assert_close_frac(out[k].cpu(), ref[k], TOL, 2e-2, k)  # (last-bit differences of the folded projection flip a discrete decision here and there)
+    # the per-frame cache keyed on KRT's identity still hits with the folded dictionary
+    fd1 = net.frame_data(f["img_in"], net.fold_transf(f["cam_in"]), f["targets"], f["feat_geo"], f["feat_tex"], f["sp_data"], f["src_foreground_mask"])
+    fd2 = net.frame_data(f["img_in"], net.fold_transf(f["cam_in"]), f["targets"], f["feat_geo"], f["feat_tex"], f["sp_data"], f["src_foreground_mask"])
+    assert fd1 is fd2
 
 
 def test_model_training_patch_and_noise(net):

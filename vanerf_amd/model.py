@@ -167,7 +167,10 @@ class VANeRF(nn.Module):
         self.init_weights(self.mlp_geo, "kaiming", nl="relu")
         self.init_weights(self.mlp_tex, "kaiming", nl="leaky_relu")
         self.vgg_loss = None  # perceptual term of forward()'s loss: a callable (pred, target) -> scalar, attached by the caller
-        self.precision = model_cfg.get("mfma_precision", "fp32")  # "fp32" | "bf16x3" (renderer.PRECISIONS); not a reference key
+        # "bf16x3" (default: bf16 MFMA on hi + lo split operands, within 3.3e-5 of the fp32 kernel on every sample, 1e-4 of the oracle with
+        # identical rays, bit-reproducible; the configuration every published number is measured in) | "fp32" (fp32 MFMA, 2.2x slower);
+        # renderer.PRECISIONS; not a reference key
+        self.precision = model_cfg.get("mfma_precision", "bf16x3")
         self._packed = None  # (version key, PackedWeights)
         self._frame_cache = None
         self._encoders_graphed = False
@@ -285,6 +288,30 @@ class VANeRF(nn.Module):
             self._packed = (key, R.PackedWeights(sd, mode=self.precision))
         return self._packed[1]
 
+    def fold_transf(self, cam):
+        """cam['transf'] (B,2,3): the optional 2-D affine the reference applies to every projected point, xy' = A (x/z, y/z) + t
+        (src/model.py:783-785, 848-850, 979-981, 1249-1251, 1261-1263).  It composes into the projection itself -- xy' = (A (x, y) + t z) / z -- so the
+        kernels, which take KRT by value, never see it: rows 0 and 1 of KRT become A KRT[:2] + t KRT[2].  (Rounding differs from the reference's
+        two-step form in the last bits; checked against the oracle, which applies the affine as written.)  No shipped config sets the key.
+        The folded dict is kept while the same KRT / transf tensors come in, so the per-frame cache keyed on KRT's identity still hits."""
+        if "transf" not in cam:
+            return cam
+        KRT, t = cam["KRT"], cam["transf"]
+        key = (KRT.data_ptr(), KRT._version, tuple(KRT.shape), t.data_ptr(), t._version, tuple(t.shape))
+        hit = getattr(self, "_transf_cache", None)
+        if hit is None or hit[0] != key:
+            M = torch.eye(3, dtype=KRT.dtype, device=KRT.device).repeat(KRT.shape[0], 1, 1)
+            M[:, :2, :2] = t[:, :2, :2].to(KRT)
+            M[:, :2, 2] = t[:, :, 2].to(KRT)
+            new = KRT.clone()
+            new[:, :3, :] = M @ KRT[:, :3, :]
+            folded = {k: v for k, v in cam.items() if k != "transf"}
+            folded["KRT"] = new
+            self._transf_cache = hit = (key, folded, (KRT, t))  # the inputs are kept alive with the entry (their addresses are the key)
+        out = dict(hit[1])
+        out.update({k: v for k, v in cam.items() if k not in ("transf", "KRT")})
+        return out
+
     def frame_data(self, img_in, cam_in, targets, feat_geo, feat_tex, sp_data, fg_mask):
         """Per-source-frame device data (vertex features, visibility, acceleration structure); cached on the identity of its inputs
         because render_pifu_nerf / render_novel_views call batch_render_pifu_nerf many times per source frame."""
@@ -308,7 +335,7 @@ class VANeRF(nn.Module):
         assert n_views == 1 and pts.shape[0] == 1, "the non-spconv path is single-view (src/networks.py:86,94)"
         feat_geo = self.feat_geo if feat_geo is None else feat_geo
         feat_tex = self.feat_tex if feat_tex is None else feat_tex
-        fd = self.frame_data(tx_data["img"], cam, targets, feat_geo, feat_tex, sp_data, kwargs["src_foreground_mask"])
+        fd = self.frame_data(tx_data["img"], self.fold_transf(cam), targets, feat_geo, feat_tex, sp_data, kwargs["src_foreground_mask"])
         p = pts[0].contiguous().float()
         if query_sdf is None or query_vis is None:
             q_sdf, q_vis, knn = R.mesh_query_accel(fd.accel, fd.verts3, fd.faces, fd.vert_vis, p)
@@ -358,8 +385,7 @@ class VANeRF(nn.Module):
         """src/model.py:1102-1422.  Same config keys (sample_per_ray_c/f, fine, uniform, rand_noise_std, src_foreground_mask, bounds, msk)."""
         batch_size = cam_tar["K"].shape[0]
         assert batch_size == 1 and n_views == 1, "val_batch_size = 1 and one source view (configs/vanerf.json:24; src/model.py:1044)"
-        if "transf" in cam_in or "transf" in cam_tar:  # the 2-D affine of src/model.py:783-785, 848-850, 1249-1251 (no shipped config sets it)
-            raise NotImplementedError("cam['transf'] is not folded into the HIP projection; fold it into KRT or drop the key")
+        cam_in = net.fold_transf(cam_in)  # (cam_tar['transf'] is not read by the reference's march either: rays come from K and RT, src/model.py:1203-1213)
         Sc = config.get("sample_per_ray_c", 64)
         Sf = config.get("sample_per_ray_f", 64)
         fine = config.get("fine", False)
@@ -473,6 +499,8 @@ class VANeRF(nn.Module):
         vert3d = targets["vert_world"]
         vimg = vert3d @ cam_tar["KRT"][:, :3, :3].transpose(1, 2) + cam_tar["KRT"][:, :3, 3][:, None]
         ret["vert_xy"] = vimg[..., :2] / (vimg[..., 2:3] + 1e-8)
+        if "transf" in cam_tar:  # src/model.py:1093-1095
+            ret["vert_xy"] = ret["vert_xy"] @ cam_tar["transf"][:, :2, :2].transpose(1, 2) + cam_tar["transf"][:, :, 2][:, None]
         ret["vert_vis"] = out["vert_vis"]
         return ret
 
