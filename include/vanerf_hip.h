@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define VANERF_ABI_VERSION 8
+#define VANERF_ABI_VERSION 9
 
 #define VANERF_OK 0
 #define VANERF_EINVAL (-22)
@@ -184,9 +184,12 @@ int vanerf_mesh_accel_build(const float* verts, int nv, const int32_t* faces, in
  * grid_nx, grid_ny, grid_s: optional layout hint (0,0,0 = none): pts are the samples of a grid_nx x grid_ny ray grid with grid_s
  * samples per ray in the reference's order (sample index = ray * grid_s + depth); lets a wave work on 64 neighbouring points.
  * The results do not depend on the hint.                                                                                      */
+/* queue_word: 8 bytes of device memory owned by the caller for the duration of the launch (8-byte aligned; any contents): the head of the
+ * kernel's work queue.  The library zeroes it on `stream` ahead of the launch and keeps NO device-side state of its own, so any number
+ * of launches may be in flight on any number of streams as long as each has its own word (vanerf_render_pass takes them from its scratch). */
 int vanerf_mesh_query_accel(const VanerfMeshAccel* accel, const float* verts, int nv, const int32_t* faces, int nf,
                             const float* vert_vis, const float* pts, int64_t n, float* sdf, uint8_t* vis, int32_t* face,
-                            int32_t* knn_idx, int grid_nx, int grid_ny, int grid_s, void* stream);
+                            int32_t* knn_idx, int grid_nx, int grid_ny, int grid_s, void* queue_word, void* stream);
 
 /* a10 knn_points K=1 (src/networks.py:28): verts[NV][4], pts[N][3] -> idx[N] int32 (first minimum). */
 int vanerf_knn1(const float* verts4, int nv, const float* pts, int64_t n, int32_t* idx, void* stream);
@@ -200,7 +203,7 @@ int vanerf_knn1(const float* verts4, int nv, const float* pts, int64_t n, int32_
  *     valid[N] (u8, may be NULL)                                                                                          */
 int vanerf_query_samples(const VanerfWeights* w, const VanerfFrame* frame, const float* pts, const float* query_sdf,
                          const uint8_t* query_vis, const int32_t* knn_idx, const float* noise, const int32_t* order, int raw, int64_t n,
-                         float* out, uint8_t* valid, void* stream);
+                         float* out, uint8_t* valid, void* queue_word /* as for vanerf_mesh_query_accel */, void* stream);
 
 /* Validity partition for vanerf_query_samples: order[N] = the samples whose projection hits the source view and its foreground mask
  * (src/model.py:780-803), in their order, then the others, in their order.  A 32-sample group of vanerf_query_samples in which no sample

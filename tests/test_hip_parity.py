@@ -900,8 +900,9 @@ def test_model_cam_transf_is_folded_into_the_projection(net, sd_full):
         assert out[k].shape == ref[k].shape, k
         assert_close_frac(out[k].cpu(), ref[k], TOL, 2e-2, k)  # (last-bit differences of the folded projection flip a discrete decision here and there)
     # the per-frame cache keyed on KRT's identity still hits with the folded dictionary
-    fd1 = net.frame_data(f["img_in"], net.fold_transf(f["cam_in"]), f["targets"], f["feat_geo"], f["feat_tex"], f["sp_data"], f["src_foreground_mask"])
-    fd2 = net.frame_data(f["img_in"], net.fold_transf(f["cam_in"]), f["targets"], f["feat_geo"], f["feat_tex"], f["sp_data"], f["src_foreground_mask"])
+    with torch.no_grad():  # (under autograd the per-frame tables are rebuilt every time: a training step changes what they are made from)
+        fd1 = net.frame_data(f["img_in"], net.fold_transf(f["cam_in"]), f["targets"], f["feat_geo"], f["feat_tex"], f["sp_data"], f["src_foreground_mask"])
+        fd2 = net.frame_data(f["img_in"], net.fold_transf(f["cam_in"]), f["targets"], f["feat_geo"], f["feat_tex"], f["sp_data"], f["src_foreground_mask"])
     assert fd1 is fd2
 
 
@@ -1035,6 +1036,34 @@ def test_training_noise_keeps_the_coarse_reuse(R, sd_full, precision):
     for k in ("color", "color_fine", "alpha_fine", "sdf"):
         assert torch.equal(d[k], e[k]), k
     assert not torch.equal(d["color_fine"], a["color_fine"])
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_many_passes_in_flight_on_two_streams(R, sd_full, precision):
+    """The library keeps no device-side state between launches: every launch with a work queue (mesh query, per-sample networks) gets its queue
+    word from its caller (vanerf_render_pass: from its scratch block).  80 small passes enqueued back to back on EACH of two streams -- 640
+    work-queue launches in flight -- give the bits of the same passes run one by one."""
+    frames = [_frame(3, 64), _frame(5, 64, 70.0, True)]
+    fdats = [_frame_data(R, sd_full, f) for f in frames]
+    w = R.PackedWeights(sd_full, mode=precision)
+    run = lambda i: R.render_pass_c(w, fdats[i % 2], frames[i % 2]["cam_tar"], frames[i % 2]["bounds"], i % 3, (i // 3) % 2, 4, 14, 15, 8, 8)
+    serial = []
+    for i in range(4):  # the distinct configurations, one at a time
+        o = run(i)
+        torch.cuda.synchronize()
+        serial.append({k: v.clone() for k, v in o.items()})
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    outs = [[], []]
+    for i in range(80):
+        for si, st in enumerate(streams):
+            with torch.cuda.stream(st):
+                outs[si].append(run((i + si) % 4))
+    torch.cuda.synchronize()
+    for si in range(2):
+        for i, o in enumerate(outs[si]):
+            ref = serial[(i + si) % 4]
+            for k in ref:
+                assert torch.equal(o[k], ref[k]), (si, i, k)
 
 
 def test_scatter_add_rows(R):

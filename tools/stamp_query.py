@@ -23,10 +23,11 @@ q_sdf, q_vis, knn = R.mesh_query_accel(fdat.accel, fdat.verts3, fdat.faces, fdat
 n = pts.shape[0]
 out = torch.empty(n, 5, device="cuda")
 nw = ctypes.c_int(0)
+qword = torch.zeros(2, dtype=torch.int32, device="cuda")
 fn = lib.vanerf_debug_query_stamps
 fn.restype = ctypes.c_int
 args = lambda st: (w.handle, ctypes.byref(fdat.c), ctypes.c_void_p(pts.data_ptr()), ctypes.c_void_p(q_sdf.data_ptr()), ctypes.c_void_p(q_vis.data_ptr()), ctypes.c_void_p(knn.data_ptr()),
-                   ctypes.c_int64(n), ctypes.c_void_p(out.data_ptr()), st, ctypes.byref(nw), None)
+                   ctypes.c_int64(n), ctypes.c_void_p(out.data_ptr()), st, ctypes.byref(nw), ctypes.c_void_p(qword.data_ptr()), None)
 assert fn(*args(None)) == 0
 stamps = torch.zeros(nw.value, 12, dtype=torch.int64, device="cuda")
 assert fn(*args(ctypes.c_void_p(stamps.data_ptr()))) == 0

@@ -12,7 +12,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int64, c_uint
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VANERF_HIP_LIB") or os.path.join(_HERE, "lib", "libvanerf_hip.so")  # the override is for A/B runs of kernel builds (tools/)
-ABI_VERSION = 8
+ABI_VERSION = 9
 NUM_LAYERS = 20
 
 if not os.path.exists(LIB_PATH):
@@ -85,9 +85,9 @@ _SIGS = {
     "vanerf_vertex_visibility": (c_int, [_FP, _FP, c_int, _FP, c_int, c_int, _FP, _FP, c_void_p]),
     "vanerf_mesh_query": (c_int, [_FP, c_int, _FP, c_int, _FP, _FP, c_int64, _FP, _FP, _FP, c_void_p]),
     "vanerf_mesh_query_accel": (c_int, [POINTER(VanerfMeshAccel), _FP, c_int, _FP, c_int, _FP, _FP, c_int64, _FP, _FP, _FP, _FP, c_int, c_int, c_int,
-                                        c_void_p]),
+                                        _FP, c_void_p]),
     "vanerf_knn1": (c_int, [_FP, c_int, _FP, c_int64, _FP, c_void_p]),
-    "vanerf_query_samples": (c_int, [c_void_p, POINTER(VanerfFrame), _FP, _FP, _FP, _FP, _FP, _FP, c_int, c_int64, _FP, _FP, c_void_p]),
+    "vanerf_query_samples": (c_int, [c_void_p, POINTER(VanerfFrame), _FP, _FP, _FP, _FP, _FP, _FP, c_int, c_int64, _FP, _FP, _FP, c_void_p]),
     "vanerf_query_order": (c_int, [POINTER(VanerfFrame), _FP, c_int64, _FP, _FP, c_int64, c_void_p]),
     "vanerf_query_order_scratch": (c_int64, [c_int64]),
     "vanerf_composite": (c_int, [_FP, _FP, _FP, c_int, c_int, c_float, _FP, _FP, _FP, _FP, _FP, c_void_p]),

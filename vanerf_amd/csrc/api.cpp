@@ -35,12 +35,10 @@ extern "C" int vanerf_weights_pack(const VanerfWeightTable* w, int mode, VanerfW
         hipError_t e = hipGetDevice(&h->device);
         if (e == hipSuccess) e = hipMalloc(&h->dev, host.size() * sizeof(float));
         if (e == hipSuccess) e = hipMemcpy(h->dev, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMalloc(&h->queues, VanerfWeights::N_QUEUES * sizeof(unsigned));
         if (e == hipSuccess) e = hipMalloc(&h->stats, sizeof(unsigned long long));
         if (e == hipSuccess) e = hipMemset(h->stats, 0, sizeof(unsigned long long));
         if (e != hipSuccess) {
             if (h->dev) (void)hipFree(h->dev);
-            if (h->queues) (void)hipFree(h->queues);
             if (h->stats) (void)hipFree(h->stats);
             delete h;
             hip_check(e, "vanerf_weights_pack: device upload");
@@ -54,7 +52,6 @@ extern "C" int vanerf_weights_free(VanerfWeights* w)
     return guarded([&] {
         if (!w) return;
         if (w->dev) HIP_CHECK(hipFree(w->dev));
-        if (w->queues) HIP_CHECK(hipFree(w->queues));
         if (w->stats) HIP_CHECK(hipFree(w->stats));
         delete w;
     });

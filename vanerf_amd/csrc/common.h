@@ -74,9 +74,5 @@ struct VanerfWeights {
     int mode = 0;
     float beta = 0.1f;
     int device = 0;
-    // work-queue heads of query_kernel (one per launch, used round robin; zeroed on the launch stream before each use)
-    static constexpr int N_QUEUES = 64;
-    unsigned* queues = nullptr;
-    mutable std::atomic<unsigned> next_queue{0}; // two host threads may launch with the same handle: each launch takes its own slot
     unsigned long long* stats = nullptr; // [0]: running count of 32-sample groups that took query_kernel's all-invalid short path
 };

@@ -338,7 +338,6 @@ __device__ __forceinline__ float box_dist2(f3 p, const float* b)
 #ifndef VANERF_MA_ATTR
 #define VANERF_MA_ATTR
 #endif
-__device__ unsigned long long g_ma_queue[64]; // work-queue heads of mesh_query_accel_kernel, one per launch in flight (vanerf_mesh_query_accel)
 
 template <int ND> // 1 or ND_MAX: small launches take one depth per item (twice the items: a launch of a few thousand items is bound by the latency of single items)
 __global__ __launch_bounds__(MA_BLOCK) VANERF_MA_ATTR void mesh_query_accel_kernel(const VanerfMeshAccel A, const float* __restrict__ V,
@@ -1099,7 +1098,7 @@ extern "C" int vanerf_knn1(const float* verts4, int nv, const float* pts, int64_
 
 extern "C" int vanerf_mesh_query_accel(const VanerfMeshAccel* accel, const float* verts, int nv, const int32_t* faces, int nf,
                                        const float* vert_vis, const float* pts, int64_t n, float* sdf, uint8_t* vis, int32_t* face,
-                                       int32_t* knn_idx, int grid_nx, int grid_ny, int grid_s, void* stream)
+                                       int32_t* knn_idx, int grid_nx, int grid_ny, int grid_s, void* queue_word, void* stream)
 {
     return guarded([&] {
         if (n == 0) return; // an empty batch is valid (and has null data pointers)
@@ -1120,26 +1119,22 @@ extern "C" int vanerf_mesh_query_accel(const VanerfMeshAccel* accel, const float
         if (grid_nx != 0 && (grid_nx < 0 || grid_ny <= 0 || grid_s <= 0 || (long long)grid_nx * grid_ny * grid_s != n))
             throw_error("vanerf_mesh_query_accel: ray-grid hint %d x %d x %d does not match n = %lld", grid_nx, grid_ny, grid_s, (long long)n);
         if (n >= (1ll << 36)) throw_error("vanerf_mesh_query_accel: n = %lld points in one launch (limit 2^36)", (long long)n);
-        // as many blocks as the chip holds at once (the work queue hands out the points); one of 64 queue slots per launch, zeroed on the stream
-        struct PerDevice { std::atomic<unsigned long long*> queue{nullptr}; std::atomic<size_t> lds{0}; std::atomic<int> resident{0}; };
-        static PerDevice per_device[64]; // looked up once per device (and again when the mesh, hence the LDS footprint, changes)
+        // as many blocks as the chip holds at once (the work queue hands out the points; its head is the caller's queue_word, zeroed on the stream)
+        if (!queue_word || (reinterpret_cast<uintptr_t>(queue_word) & 7u)) throw_error("vanerf_mesh_query_accel: queue_word must be 8 bytes of device memory, 8-byte aligned");
+        struct PerDevice { std::atomic<size_t> lds{~(size_t)0}; std::atomic<int> resident{0}; };
+        static PerDevice per_device[64]; // host-side cache of the occupancy query, per device (and again when the mesh, hence the LDS footprint, changes)
         int dev = 0;
         HIP_CHECK(hipGetDevice(&dev));
         PerDevice& pd = per_device[dev & 63];
-        if (pd.queue.load() == nullptr || pd.lds.load() != lds) {
+        if (pd.resident.load() == 0 || pd.lds.load() != lds) {
             int cus = 256, per_cu = 1;
-            void* qptr = nullptr;
-            HIP_CHECK(hipGetSymbolAddress(&qptr, HIP_SYMBOL(g_ma_queue)));
             HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
             HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mesh_query_accel_kernel<ND_MAX>, MA_BLOCK, lds));
             pd.resident.store(cus * (per_cu > 0 ? per_cu : 1));
             pd.lds.store(lds);
-            pd.queue.store(static_cast<unsigned long long*>(qptr));
         }
-        unsigned long long* const queue_base = pd.queue.load();
         const int resident = pd.resident.load();
-        static std::atomic<unsigned> next_slot{0};
-        unsigned long long* const queue = queue_base + (next_slot.fetch_add(1u) % 64u);
+        unsigned long long* const queue = static_cast<unsigned long long*>(queue_word);
         HIP_CHECK(hipMemsetAsync(queue, 0, sizeof(unsigned long long), (hipStream_t)stream));
         long long blocks = (n + MA_BLOCK - 1) / MA_BLOCK;
         if (blocks > resident) blocks = resident;

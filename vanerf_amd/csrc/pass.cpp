@@ -28,6 +28,7 @@ struct Layout {
     float *rays_d, *cam_pos, *near, *far, *pts, *q_sdf_c, *rgba_c, *contrib, *z_new, *q_sdf_f, *rgba_f, *z_fine, *color_f3, *s1;
     uint8_t *q_vis;
     int32_t *knn, *order, *src;
+    unsigned long long* queue_words; // work-queue heads of the pass's four big launches (mesh query and per-sample networks, coarse and fine)
     void* order_scratch;
     int64_t order_scratch_bytes, total;
 };
@@ -37,6 +38,7 @@ Layout carve(void* base, int R, int Sc, int Sf, int fine, int reuse)
     Carver c(base);
     Layout L{};
     const int64_t nc = (int64_t)R * Sc, nf = fine ? (int64_t)R * (reuse ? Sf : Sc + Sf) : 0, nmax = nc > nf ? nc : nf;
+    L.queue_words = c.take<unsigned long long>(4);
     L.rays_d = c.take<float>(3LL * R);
     L.cam_pos = c.take<float>(4);
     L.near = c.take<float>(R);
@@ -103,18 +105,20 @@ extern "C" int vanerf_render_pass(const VanerfWeights* w, const VanerfFrame* fra
             ok(vanerf_ray_setup(d.x0, d.y0, d.step_x, d.step_y, d.y_block, d.nx, d.ny, d.width, d.invK_T, d.RT, d.znear, d.zfar, d.bounds, Sc, d.t_lin_c,
                                 d.jitter, o.index, L.rays_d, L.cam_pos, L.near, L.far, o.hit, o.z, stream), "ray setup");
         // one march: points, mesh query (+ 1-NN), validity partition, per-sample networks
+        int marches = 0; // every launch with a work queue gets a word of its own from the scratch block (nothing is shared between launches in flight)
         auto march = [&](const float* z, int S, const float* noise, float* q_sdf, float* rgba) {
+            unsigned long long* const qw = L.queue_words + 2 * marches++;
             const int64_t n = (int64_t)R * S;
             ok(vanerf_sample_points(L.rays_d, L.cam_pos, z, R, S, L.pts, stream), "sample points");
             const bool grid = d.pixels_xy == nullptr;
             ok(vanerf_mesh_query_accel(accel, verts, nv, faces, nf, frame->vert_vis, L.pts, n, q_sdf, L.q_vis, nullptr, L.knn, grid ? d.nx : 0,
-                                       grid ? d.ny : 0, grid ? S : 0, stream), "mesh query");
+                                       grid ? d.ny : 0, grid ? S : 0, qw, stream), "mesh query");
             const int32_t* order = nullptr;
             if (n >= PARTITION_MIN_SAMPLES) {
                 ok(vanerf_query_order(frame, L.pts, n, L.order, L.order_scratch, L.order_scratch_bytes, stream), "validity partition");
                 order = L.order;
             }
-            ok(vanerf_query_samples(w, frame, L.pts, q_sdf, L.q_vis, L.knn, noise, order, 0, n, rgba, nullptr, stream), "per-sample networks");
+            ok(vanerf_query_samples(w, frame, L.pts, q_sdf, L.q_vis, L.knn, noise, order, 0, n, rgba, nullptr, qw + 1, stream), "per-sample networks");
         };
         march(o.z, Sc, d.noise_c, L.q_sdf_c, L.rgba_c);
         ok(vanerf_composite(L.rgba_c, o.z, L.q_sdf_c, R, Sc, w->beta, o.color, o.depth, o.alpha, L.s1, L.contrib, stream), "coarse composite");

@@ -1081,12 +1081,13 @@ __global__ __launch_bounds__(64 * WPB<MODE>, MODE == 1 ? VANERF_WAVES_PER_SIMD_B
 
 extern "C" int vanerf_query_samples(const VanerfWeights* w, const VanerfFrame* frame, const float* pts, const float* query_sdf,
                                     const uint8_t* query_vis, const int32_t* knn_idx, const float* noise, const int32_t* order, int raw, int64_t n,
-                                    float* out, uint8_t* valid, void* stream)
+                                    float* out, uint8_t* valid, void* queue_word, void* stream)
 {
     return guarded([&] {
         if (n < 0) throw_error("vanerf_query_samples: n = %lld < 0", (long long)n);
         if (n == 0) return; // an empty batch is valid (and has null data pointers)
         if (!w || !w->dev || !frame || !pts || !query_sdf || !query_vis || !knn_idx || !out) throw_error("vanerf_query_samples: null argument");
+        if (!queue_word || (reinterpret_cast<uintptr_t>(queue_word) & 7u)) throw_error("vanerf_query_samples: queue_word must be 8 bytes of device memory, 8-byte aligned");
         if ((n + 31) / 32 >= 0xffffff00LL) throw_error("vanerf_query_samples: n = %lld too large for one launch", (long long)n);
         const VanerfFrame& f = *frame;
         if (!f.geo0 || !f.geo1 || !f.tex || !f.img || !f.mask || !f.verts || !f.vfeat0 || !f.vfeat1 || !f.vfeat_tex || !f.vert_vis || !f.kpt_cam)
@@ -1112,8 +1113,8 @@ extern "C" int vanerf_query_samples(const VanerfWeights* w, const VanerfFrame* f
         if (const char* e = getenv("VANERF_BLOCKS_PER_CU")) per_cu = atoi(e) > 0 ? atoi(e) : 2; // experiment knob
         long long cap = (long long)cus * per_cu;
         if (blocks > cap) blocks = cap;
-        P.queue = w->queues + (w->next_queue.fetch_add(1u, std::memory_order_relaxed) % VanerfWeights::N_QUEUES);
-        HIP_CHECK(hipMemsetAsync(P.queue, 0, sizeof(unsigned), (hipStream_t)stream));
+        P.queue = static_cast<unsigned*>(queue_word); // the caller's word: no launch shares a queue head with another (any number in flight, any streams)
+        HIP_CHECK(hipMemsetAsync(P.queue, 0, 8, (hipStream_t)stream));
         if (w->mode == 1) {
             // the opt-in above 64 KB of dynamic LDS is per device: set on every call (cheap), as vanerf_mesh_query_accel does
             HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(query_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DYN_LDS_BYTES));
@@ -1218,7 +1219,7 @@ extern "C" int64_t vanerf_query_order_scratch(int64_t n) { return n + 4 * ((n + 
 #ifdef VANERF_STAMPS
 // Diagnostic build: same launch with a per-wave phase-cycle table [waves][12] (device pointer, zero-initialised by the caller).
 extern "C" int vanerf_debug_query_stamps(const VanerfWeights* w, const VanerfFrame* frame, const float* pts, const float* query_sdf,
-                                         const uint8_t* query_vis, const int32_t* knn_idx, int64_t n, float* out, unsigned long long* stamps, int* n_waves, void* stream)
+                                         const uint8_t* query_vis, const int32_t* knn_idx, int64_t n, float* out, unsigned long long* stamps, int* n_waves, void* queue_word, void* stream)
 {
     return guarded([&] {
         QueryParams P;
@@ -1233,8 +1234,8 @@ extern "C" int vanerf_debug_query_stamps(const VanerfWeights* w, const VanerfFra
         if (const char* e = getenv("VANERF_BLOCKS_PER_CU")) capd = 256LL * (atoi(e) > 0 ? atoi(e) : 2);
         if (blocks > capd) blocks = capd;
         *n_waves = (int)blocks * wpb;
-        P.queue = w->queues + (w->next_queue.fetch_add(1u, std::memory_order_relaxed) % VanerfWeights::N_QUEUES);
-        HIP_CHECK(hipMemsetAsync(P.queue, 0, sizeof(unsigned), (hipStream_t)stream));
+        P.queue = static_cast<unsigned*>(queue_word);
+        HIP_CHECK(hipMemsetAsync(P.queue, 0, 8, (hipStream_t)stream));
         if (stamps && w->mode == 1) HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(query_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DYN_LDS_BYTES));
         if (stamps && w->mode == 1) hipLaunchKernelGGL(query_kernel<1>, dim3((unsigned)blocks), dim3(64 * WPB<1>), DYN_LDS_BYTES, (hipStream_t)stream, P);
         else if (stamps) hipLaunchKernelGGL(query_kernel<0>, dim3((unsigned)blocks), dim3(64 * WPB<0>), 0, (hipStream_t)stream, P);

@@ -321,9 +321,15 @@ class VANeRF(nn.Module):
                 sp_data["extrin"], fg_mask)
         scalars = tuple(float(cam_in[k]) for k in ("width", "height", "znear", "zfar", "nml_scale")) + tuple(sorted(self.kwargs["sp_args"].items()))
         key = tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in deps) + (scalars, tuple(p._version for p in self.tex_vis_fusion.parameters()))
-        if self._frame_cache is None or self._frame_cache[0] != key:
+        # Under autograd nothing is kept: a training step changes the encoders' weights, and with graph_encoders the feature maps are the
+        # captured graph's static output buffers -- same address, same version counter after every replay -- so the key above cannot see it.
+        fresh = torch.is_grad_enabled()  # (forward() hands this method DETACHED maps, so requires_grad says nothing here)
+        if fresh or self._frame_cache is None or self._frame_cache[0] != key:
             sd = {"tex_vis_fusion." + k: v for k, v in self.tex_vis_fusion.state_dict().items()}
             fd = R.FrameData(sd, img_in, feat_geo, feat_tex, fg_mask, cam_in, targets, sp_data, self.kwargs["sp_args"])
+            if fresh:
+                self._frame_cache = None
+                return fd
             self._frame_cache = (key, fd, deps)
         return self._frame_cache[1]
 

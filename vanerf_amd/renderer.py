@@ -324,6 +324,12 @@ def mesh_query(verts3, faces_i32, vert_vis, pts, want_face=False):
     return (sdf, vis, face) if want_face else (sdf, vis)
 
 
+def _queue_word(dev):
+    """Eight bytes of device memory for the work-queue head of ONE launch (vanerf_mesh_query_accel / vanerf_query_samples zero it on the stream).
+    A fresh block per call: the caching allocator hands it out again only to later work of the same stream, so no two launches in flight share one."""
+    return torch.empty(2, dtype=torch.int32, device=dev)
+
+
 def mesh_query_accel(accel, verts3, faces_i32, vert_vis, pts, want_face=False, want_knn=True, grid=None):
     """Same results as mesh_query (+ knn1), through the per-frame acceleration structure: sdf, vis[, face][, knn].
     grid = (nx, ny, S): pts are the samples of an nx x ny ray grid, S per ray, ray-major (speed hint only)."""
@@ -335,7 +341,7 @@ def mesh_query_accel(accel, verts3, faces_i32, vert_vis, pts, want_face=False, w
     knn = torch.empty(n, dtype=torch.int32, device=pts.device) if want_knn else None
     check(lib.vanerf_mesh_query_accel(byref(accel.c), _ptr(verts3, torch.float32), verts3.shape[0], _ptr(faces_i32, torch.int32),
                                       faces_i32.shape[0], _ptr(vert_vis, torch.float32), _ptr(pts, torch.float32), n, _ptr(sdf), _ptr(vis),
-                                      _ptr(face), _ptr(knn), int(gnx), int(gny), int(gs), _stream()))
+                                      _ptr(face), _ptr(knn), int(gnx), int(gny), int(gs), _ptr(_queue_word(pts.device)), _stream()))
     return tuple(t for t in (sdf, vis, face, knn) if t is not None)
 
 
@@ -366,7 +372,7 @@ def query_samples(weights, frame, pts, query_sdf, query_vis, knn_idx, noise=None
         raise ValueError("order must hold one index per sample")
     check(lib.vanerf_query_samples(weights.handle, byref(frame.c), _ptr(pts, torch.float32), _ptr(query_sdf, torch.float32),
                                    _ptr(query_vis, torch.uint8), _ptr(knn_idx, torch.int32), _ptr(noise, torch.float32), _ptr(order, torch.int32),
-                                   int(bool(raw)), n, _ptr(out), _ptr(valid), _stream()))
+                                   int(bool(raw)), n, _ptr(out), _ptr(valid), _ptr(_queue_word(pts.device)), _stream()))
     return (out, valid) if want_valid else out
 
 
@@ -689,6 +695,9 @@ def scatter_add_rows(table, idx, g, w=None):
     """table[idx[i]] += w[i] * g[i] (vanerf_scatter_add_rows): the backward of a row gather over ~1e6 samples into a table of ~1e3..1e4 rows."""
     n, C = g.shape
     assert table.shape[1] == C and idx.shape == (n,) and table.is_contiguous()
+    if table.shape[0] * 4 > 128 * 1024:  # a table of more than 32 768 rows (a feature map beyond 181 x 181) does not fit the kernel's LDS slice
+        table.index_add_(0, idx.long(), g if w is None else g * w.reshape(-1, 1))
+        return table
     check(lib.vanerf_scatter_add_rows(_ptr(idx, torch.int32), _ptr(w, torch.float32), _ptr(g.contiguous(), torch.float32), n, C,
                                       _ptr(table, torch.float32), table.shape[0], _stream()))
     return table
