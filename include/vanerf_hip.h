@@ -286,6 +286,27 @@ int vanerf_render_pass(const VanerfWeights* w, const VanerfFrame* frame, const V
  * slices of the table instead of contended global atomics.                                                                               */
 int vanerf_scatter_add_rows(const int32_t* idx, const float* w, const float* g, int64_t n, int C, float* table, int R, void* stream);
 
+/* f-4, the fused backward pass of the per-sample networks (training; reference: autograd through VANeRF.query, src/model.py:748-957, driven by
+ * training_step, src/model.py:381-459).  Two launches per block of n samples, on one stream, with an fp32 weight handle (vanerf_weights_pack mode 0):
+ *   vanerf_query_forward_spill  the forward pass once more (raw outputs [sdf_pred, rad, r, g, b], validity), which also writes every layer's operands
+ *                               X and the gates / pixel weight / pre-pooling latent the backward needs:  xs[x_rows][npad], aux[aux_rows][npad]
+ *   vanerf_query_backward       d[n][5]: gradient with respect to eval_func's outputs [alpha, sdf, r, g, b] (src/model.py:1140-1160; d2 / noise /
+ *                               noise2 may be NULL: a second set of draws on the same points, the density noise) with raw / valid of the spill pass
+ *                               -> ys[y_rows][npad]: every layer's output gradient, and
+ *                               ig[ig_rows][npad]: the gradients of the gathered inputs (pixel taps, nearest / twin vertex rows)
+ * Channel-major fp32 spills, npad = n rounded up to a multiple of 32 (columns >= n carry zero gradients); row counts: vanerf_spill_rows.
+ * The weight gradient of layer l is then one matrix product over the samples, dW'[out][slot] = ys_l xs_l^T with the rows of
+ * vanerf_layer_rows and the slot -> input-channel table of vanerf_layer_slots (slot 2 t + h; -1 unused, -2 bias: that column is the bias
+ * gradient); vanerf_amd/hip_backward.py does this with torch.bmm and hands ig to vanerf_scatter_add_rows.                                */
+int vanerf_query_forward_spill(const VanerfWeights* w, const VanerfFrame* frame, const float* pts, const float* query_sdf,
+                               const uint8_t* query_vis, const int32_t* knn_idx, int64_t n, int64_t npad, float* out_raw, uint8_t* valid,
+                               float* xs, float* aux, void* queue_word, void* stream);
+int vanerf_query_backward(const VanerfWeights* w, const float* d, const float* d2, const float* noise, const float* noise2, const float* raw,
+                          const uint8_t* valid, int64_t n, int64_t npad, const float* xs, const float* aux, float* ys, float* ig, void* stream);
+int vanerf_spill_rows(int* x_rows, int* y_rows, int* aux_rows, int* ig_rows);
+int vanerf_layer_slots(int layer, int32_t* k_of_slot, int cap);              /* returns 2 T (k-pairs x lane halves), < 0: error */
+int vanerf_layer_rows(int layer, int* x_row, int* y_row, int* n_out);
+
 /* a3  ray_bbox_intersection (src/model.py:1496-1570) alone: bounds[6], orig[3] (host values), dirs[R][3] (device)
  *     -> near[R], far[R] (1.0 when the ray does not cross the box exactly twice), hit[R] (u8).                               */
 int vanerf_ray_bbox(const float* bounds, const float* orig, const float* dirs, int R, float* near, float* far, uint8_t* hit, void* stream);

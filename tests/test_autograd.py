@@ -146,6 +146,88 @@ def test_training_step_under_detect_anomaly():
     assert sum(int(not torch.equal(before[k], p.detach())) for k, p in with_grad.items()) >= 0.9 * len(with_grad)
 
 
+def _grads_of_a_step(net, frame, seed=3):
+    import numpy as np
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    out = _step(net, frame)
+    g = torch.Generator().manual_seed(1)
+    sum((out[k] * torch.randn(out[k].shape, generator=g).cuda()).sum() for k in KEYS).backward()
+    return {k: (None if p.grad is None else p.grad.clone()) for k, p in net.named_parameters()}
+
+
+def _compare_backends(a, b, rel, cos_min):
+    """Every parameter: same set with a gradient; relative L2 and cosine per tensor.  mlp_tex (the IBR head, value-dead at one view) gets none."""
+    assert set(a) == set(b)
+    worst = (0.0, 1.0)
+    gmax = max(v.norm().item() for v in a.values() if v is not None)  # noise floor of a sum over all samples: relative to the largest gradient
+    for k in a:
+        if k.startswith("mlp_tex."):
+            assert (a[k] is None or float(a[k].abs().max()) == 0.0) and (b[k] is None or float(b[k].abs().max()) == 0.0), k
+            continue
+        assert (a[k] is None) == (b[k] is None), k
+        if a[k] is None:
+            continue
+        na, nb = a[k].norm().item(), b[k].norm().item()
+        diff = (a[k] - b[k]).norm().item()
+        assert diff <= rel * max(na, nb) + 1e-4 + 1e-5 * gmax, (k, diff, na, nb, gmax)
+        if max(na, nb) < 1e-2 + 1e-3 * gmax:  # (a bias in front of a normalisation layer has a zero gradient up to rounding noise: no direction to compare)
+            continue
+        r, c = diff / max(na, nb), float((a[k] * b[k]).sum() / (na * nb))
+        worst = (max(worst[0], r), min(worst[1], c))
+        assert c >= cos_min, (k, r, c)
+    return worst
+
+
+@pytest.mark.parametrize("precision", ["bf16x3", "fp32"])
+def test_hip_backward_matches_the_pytorch_graph(precision):
+    """Row f-4: the fused HIP backward (csrc/query_backward.hip + hip_backward.py: forward spill, dX = W^T dY chain in registers, one matrix
+    product per layer for dW, HIP scatters for the gathers) against the PyTorch graph of torch_graph.networks_at on the same training step --
+    an independent second implementation differentiated by torch.autograd.  Both forward precisions (values from the bf16x3 or the fp32
+    kernel; the gradient always runs in fp32)."""
+    frame = synth.to_device(synth.make_frame(seed=3, tar_h=64, tar_w=64), "cuda")
+    res = []
+    for hip in (True, False):
+        net = _net(0.01)
+        net.precision = precision
+        net.kwargs["hip_backward"] = hip
+        res.append(_grads_of_a_step(net, frame))
+    worst = _compare_backends(res[0], res[1], 2e-3, 0.9999)
+    print(f"HIP backward vs PyTorch graph [{precision}]: worst relative L2 {worst[0]:.2e}, worst cosine {worst[1]:.6f}")
+
+
+def test_hip_backward_at_the_real_patch_size():
+    """The same comparison at the training configuration of configs/vanerf.json: a 64x64 patch, 64 + 64 samples per ray (524 288 network
+    evaluations, eight blocks of 65 536 samples through the HIP backward)."""
+    from vanerf_amd.config import default_config
+    from vanerf_amd.model import VANeRF
+    frame = synth.to_device(synth.make_frame(seed=3, tar_h=256, tar_w=256), "cuda")
+    res = []
+    for hip in (True, False):
+        torch.manual_seed(0)
+        cfg = default_config()
+        cfg["models"]["VANeRF"]["dr_kwargs"].update(sample_per_ray_c=64, sample_per_ray_f=64, rand_noise_std=0.01, uniform=False, fine=True)
+        net = VANeRF(cfg).cuda().train()
+        net.load_state_dict(synth.make_full_weights(0), strict=False)
+        net.kwargs["hip_backward"] = hip
+        dr = {"img": frame["img_in"], "cam": frame["cam_in"], "cam_tar": frame["cam_tar"], "tar": torch.rand(1, 3, 256, 256, device="cuda"),
+              "msk": torch.ones(1, 1, 256, 256, device="cuda")}
+        import numpy as np
+        torch.manual_seed(5)
+        np.random.seed(5)
+        torch.cuda.reset_peak_memory_stats()
+        out = net(frame["img_in"], frame["cam_in"], frame["hand_type"], frame["targets"], None, None, n_views=1, sp_data=dict(frame["sp_data"]),
+                  dr_data=dr, src_foreground_mask=frame["src_foreground_mask"], bounds=frame["bounds"])["out"]["nerf"]
+        assert out["tex_fg_fine"].shape == (1, 3, 64, 64)
+        g = torch.Generator().manual_seed(1)
+        sum((out[k] * torch.randn(out[k].shape, generator=g).cuda()).sum() for k in KEYS).backward()
+        res.append({k: (None if p.grad is None else p.grad.clone()) for k, p in net.named_parameters()})
+        print("hip" if hip else "torch", "backward: peak memory", round(torch.cuda.max_memory_allocated() / 2 ** 30, 2), "GiB")
+        del net, out
+    worst = _compare_backends(res[0], res[1], 5e-3, 0.9999)
+    print(f"64x64 patch, 64 + 64 samples: worst relative L2 {worst[0]:.2e}, worst cosine {worst[1]:.6f}")
+
+
 def test_chunked_backward_gives_the_same_gradients():
     """torch_graph.PassGradient takes the gradient chunk of rays by chunk of rays when `grad_rays_per_chunk` is set, and the second stage of a
     chunk block of samples by block when `grad_samples_per_block` is (bounded memory): the sum over chunks / blocks is the gradient of the
@@ -153,11 +235,17 @@ def test_chunked_backward_gives_the_same_gradients():
     frame = synth.to_device(synth.make_frame(seed=3, tar_h=64, tar_w=64), "cuda")
     grads = []
     # 64 rays: one chunk / chunks of 24 + 24 + 16 rays / blocks of 200 samples / both / blocks of 300 samples as replays of one HIP graph
-    for chunk, block, graph in ((None, None, False), (24, None, False), (None, 200, False), (40, 96, False), (None, 300, True)):
+    # ... and the fused HIP backward (the default): whole patch / chunks of rays / blocks of 256 samples / both
+    for chunk, block, graph, hip in ((None, None, False, False), (24, None, False, False), (None, 200, False, False), (40, 96, False, False),
+                                     (None, 300, True, False), (None, None, False, True), (24, None, False, True), (None, 256, False, True),
+                                     (40, 96, False, True)):
         net = _net(0.01)
         net.kwargs["grad_rays_per_chunk"] = chunk
         net.kwargs["grad_samples_per_block"] = block
         net.kwargs["grad_graph_blocks"] = graph
+        net.kwargs["hip_backward"] = hip
+        if hip and block:
+            net.kwargs["hip_backward_block"] = block
         torch.manual_seed(3)
         import numpy as np
         np.random.seed(3)
@@ -189,6 +277,7 @@ def test_geometry_branch_on_valid_samples_only_gives_the_same_gradients():
         for compact in (False, True):
             G.COMPACT_VALID = compact
             net = _net(0.01)
+            net.kwargs["hip_backward"] = False  # (this is about the PyTorch graph; the HIP backward meets the same mask at the end of the test)
             torch.manual_seed(3)
             np.random.seed(3)
             out = _step(net, frame)
@@ -201,6 +290,15 @@ def test_geometry_branch_on_valid_samples_only_gives_the_same_gradients():
     assert set(grads[0]) == set(grads[1]) and len(grads[0]) > 100
     for k in grads[0]:
         assert (grads[0][k] - grads[1][k]).norm() <= 3e-3 * grads[0][k].norm() + 1e-4, k
+    # the fused HIP backward on the same half-masked frame: samples outside the mask have pixel weight 0 and eval_func masks them
+    net = _net(0.01)
+    hip = {k: v for k, v in _grads_of_a_step(net, frame).items() if v is not None}
+    assert set(hip) == set(grads[0])
+    for k in grads[0]:
+        err = (grads[0][k] - hip[k]).norm().item()
+        # (the per-frame conv / LayerNorm stacks amplify the fp32 summation order of the table's gradient: a few 1e-3, as against the oracle above)
+        per_frame = k.startswith(("tex_vis_fusion.fconv3", "tex_vis_fusion.fconv4", "tex_vis_fusion.fconv_gt", "tex_encoder.", "geo_encoder."))
+        assert err <= (1e-2 if per_frame else 3e-3) * grads[0][k].norm().item() + 1e-4, (k, err, grads[0][k].norm().item())
 
 
 def test_graphed_encoders_give_the_same_step():

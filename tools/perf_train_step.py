@@ -14,6 +14,10 @@ for key in ("grad_rays_per_chunk", "grad_samples_per_block"):  # e.g. --grad_sam
         cfg["models"]["VANeRF"][key] = int(sys.argv[sys.argv.index("--" + key) + 1])
 if "--grad_graph_blocks" in sys.argv:  # the blocks of the backward's second stage as replays of one HIP graph
     cfg["models"]["VANeRF"]["grad_graph_blocks"] = True
+if "--torch_graph" in sys.argv:  # the PyTorch graph instead of the fused HIP backward (the independent checker)
+    cfg["models"]["VANeRF"]["hip_backward"] = False
+if "--hip_backward_block" in sys.argv:
+    cfg["models"]["VANeRF"]["hip_backward_block"] = int(sys.argv[sys.argv.index("--hip_backward_block") + 1])
 if "--graph_encoders" in sys.argv:  # the two image encoders as HIP graphs (forward and backward)
     cfg["models"]["VANeRF"]["graph_encoders"] = True
 net = VANeRF(cfg).cuda().train()
@@ -39,5 +43,5 @@ for _ in range(5):
 with torch.no_grad():
     net.eval(); torch.cuda.synchronize(); t0 = time.perf_counter()
     net.train()
-print(f"training step (64x64 patch, 64+64 samples, encoders + HIP forward + torch graph + backward + Adam): min {1e3 * min(ts):.1f} ms, loss {l:.4f}, "
+print(f"training step (64x64 patch, 64+64 samples, encoders + HIP forward + backward + Adam): min {1e3 * min(ts):.1f} ms, loss {l:.4f}, "
       f"peak memory {torch.cuda.max_memory_allocated() / 2**30:.2f} GiB")

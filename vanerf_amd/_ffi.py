@@ -88,6 +88,11 @@ _SIGS = {
                                         _FP, c_void_p]),
     "vanerf_knn1": (c_int, [_FP, c_int, _FP, c_int64, _FP, c_void_p]),
     "vanerf_query_samples": (c_int, [c_void_p, POINTER(VanerfFrame), _FP, _FP, _FP, _FP, _FP, _FP, c_int, c_int64, _FP, _FP, _FP, c_void_p]),
+    "vanerf_query_forward_spill": (c_int, [c_void_p, POINTER(VanerfFrame), _FP, _FP, _FP, _FP, c_int64, c_int64, _FP, _FP, _FP, _FP, _FP, c_void_p]),
+    "vanerf_query_backward": (c_int, [c_void_p, _FP, _FP, _FP, _FP, _FP, _FP, c_int64, c_int64, _FP, _FP, _FP, _FP, c_void_p]),
+    "vanerf_spill_rows": (c_int, [POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
+    "vanerf_layer_slots": (c_int, [c_int, _FP, c_int]),
+    "vanerf_layer_rows": (c_int, [c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
     "vanerf_query_order": (c_int, [POINTER(VanerfFrame), _FP, c_int64, _FP, _FP, c_int64, c_void_p]),
     "vanerf_query_order_scratch": (c_int64, [c_int64]),
     "vanerf_composite": (c_int, [_FP, _FP, _FP, c_int, c_int, c_float, _FP, _FP, _FP, _FP, _FP, c_void_p]),

@@ -7,13 +7,14 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib", "libvanerf_hip.so")
-SOURCES = ["api.cpp", "weights_pack.cpp", "pass.cpp", "query_kernel.hip", "render_kernels.hip", "mesh_kernels.hip", "train_kernels.hip"]
+SOURCES = ["api.cpp", "weights_pack.cpp", "pass.cpp", "query_kernel.hip", "render_kernels.hip", "mesh_kernels.hip", "train_kernels.hip", "query_backward.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-Wall", "-Wextra", "-Wno-unused-parameter"]
 # per-file flags.  query_kernel.hip: MFMA results are allocated in VGPRs (the chained layers read every accumulator element once with VALU
 # instructions; with the default AGPR form each read is a v_accvgpr_read first: 667 -> 95 per 32-sample group), and the SLP vectoriser
 # stays off (it packs adjacent f32 multiplies / adds into v_pk_* instructions, which cost more beside MFMAs than the scalar pairs).
 FILE_FLAGS = {"query_kernel.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-slp-vectorize"],
+              "query_backward.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-slp-vectorize"],
               # mesh_query_accel_kernel sits exactly at 128 registers (four waves per SIMD): loop-invariant address arithmetic goes back into the
               # work loop instead of being parked in scratch (7 spilled VGPRs without the flag; scratch fails the build, _check_no_scratch)
               "mesh_kernels.hip": ["-mllvm", "-sink-insts-to-avoid-spills"]}

@@ -24,10 +24,11 @@ extern "C" int vanerf_weights_pack(const VanerfWeightTable* w, int mode, VanerfW
         constexpr size_t n_ptrs = offsetof(VanerfWeightTable, sigmoid_beta) / sizeof(const float*);
         for (size_t i = 0; i < n_ptrs; ++i)
             if (!ptrs[i]) throw_error("vanerf_weights_pack: weight pointer #%d is null", (int)i);
-        std::vector<float> host;
+        std::vector<float> host, host_bwd;
         LayerOffsets offs{};
-        pack_weights_host(*w, host, offs, mode);
+        pack_weights_host(*w, host, offs, mode, mode == 0 ? &host_bwd : nullptr);
         auto* h = new VanerfWeights();
+        h->n_floats_bwd = host_bwd.size();
         h->n_floats = host.size();
         h->offs = offs;
         h->mode = mode;
@@ -35,10 +36,13 @@ extern "C" int vanerf_weights_pack(const VanerfWeightTable* w, int mode, VanerfW
         hipError_t e = hipGetDevice(&h->device);
         if (e == hipSuccess) e = hipMalloc(&h->dev, host.size() * sizeof(float));
         if (e == hipSuccess) e = hipMemcpy(h->dev, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice);
+        if (e == hipSuccess && !host_bwd.empty()) e = hipMalloc(&h->dev_bwd, host_bwd.size() * sizeof(float));
+        if (e == hipSuccess && !host_bwd.empty()) e = hipMemcpy(h->dev_bwd, host_bwd.data(), host_bwd.size() * sizeof(float), hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMalloc(&h->stats, sizeof(unsigned long long));
         if (e == hipSuccess) e = hipMemset(h->stats, 0, sizeof(unsigned long long));
         if (e != hipSuccess) {
             if (h->dev) (void)hipFree(h->dev);
+            if (h->dev_bwd) (void)hipFree(h->dev_bwd);
             if (h->stats) (void)hipFree(h->stats);
             delete h;
             hip_check(e, "vanerf_weights_pack: device upload");
@@ -52,6 +56,7 @@ extern "C" int vanerf_weights_free(VanerfWeights* w)
     return guarded([&] {
         if (!w) return;
         if (w->dev) HIP_CHECK(hipFree(w->dev));
+        if (w->dev_bwd) HIP_CHECK(hipFree(w->dev_bwd));
         if (w->stats) HIP_CHECK(hipFree(w->stats));
         delete w;
     });

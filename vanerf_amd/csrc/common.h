@@ -63,12 +63,15 @@ int guarded(F&& fn) noexcept
     }
 }
 
-void pack_weights_host(const VanerfWeightTable& w, std::vector<float>& out, LayerOffsets& offs, int mode = 0);
+void pack_weights_host(const VanerfWeightTable& w, std::vector<float>& out, LayerOffsets& offs, int mode = 0, std::vector<float>* bwd = nullptr);
+int layer_slots(int layer, int* k_of_slot, int cap);
 
 } // namespace vanerf
 
 struct VanerfWeights {
     float* dev = nullptr;   // packed fragment streams
+    float* dev_bwd = nullptr; // fp32 handles only: the transposed streams of the fused backward pass (query_backward.hip)
+    size_t n_floats_bwd = 0;
     size_t n_floats = 0;
     vanerf::LayerOffsets offs{};
     int mode = 0;

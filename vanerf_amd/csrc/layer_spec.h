@@ -71,4 +71,42 @@ constexpr unsigned layer_offset_b(int l)
     return o;
 }
 
+// ---- training: spills of the fused backward pass (query_backward.hip) ---------------------------------------
+// The forward kernel in spill mode writes every layer's B operands X (the layer's inputs after the previous activation, slot (t, h) = k-pair t
+// of lane half h) channel-major: Xs[x_row_base(l) + 2 t + h][sample]; the backward chain writes every layer's output gradient dY the same
+// way: Ys[y_row_base(l) + out row][sample].  The weight gradient of layer l is then ONE matrix product over the samples,
+// dW'[out][slot] = Ys_l Xs_l^T (a bias slot holds the operand 1, so its column is the bias gradient), mapped back to the reference's
+// [out][in] layout through the slot -> input-channel table of weights_pack.cpp (vanerf_layer_slots).
+constexpr int kNOUT[NUM_LAYERS] = {10, 3, 64, 64, 10, 3, 8, 8, 128, 128, 120, 64, 64, 64, 2, 24, 96, 6, 96, 3};
+constexpr int x_row_base(int l) { int o = 0; for (int i = 0; i < l; ++i) o += 2 * kT[i]; return o; }
+constexpr int y_row_base(int l) { int o = 0; for (int i = 0; i < l; ++i) o += kNOUT[i]; return o; }
+constexpr int X_ROWS = x_row_base(NUM_LAYERS), Y_ROWS = y_row_base(NUM_LAYERS);
+// k-pairs of a layer's OUTPUT rows in D-register order (block ob, register r <-> rows 32 ob + row0(r) and + 4): the K dimension of dX = W^T dY
+constexpr int kBT[NUM_LAYERS] = {6, 3, 32, 32, 6, 3, 4, 4, 64, 64, 60, 32, 32, 32, 2, 12, 48, 4, 48, 3};
+// input-slot blocks (16 k-pairs each) of a layer that need a gradient: first block, number of blocks
+constexpr int kBLO[NUM_LAYERS] = {0, 0, 0, 0, 0, 0, 0, 0, 9, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+constexpr int kBNB[NUM_LAYERS] = {6, 1, 6, 2, 1, 1, 1, 1, 3, 4, 5, 4, 4, 2, 2, 4, 3, 3, 3, 3};
+// Backward stream of layer l: passes of at most 4 slot blocks, pass p = float [kBT][64 lanes][nb_p] (A fragments of v_mfma_f32_32x32x2_f32:
+// lane (jj, hh) holds W[out row of k-pair t'' half hh][channel of slot row 32 ib + jj])
+constexpr int bwd_pass_blocks(int l, int p) { return kBNB[l] - 4 * p > 4 ? 4 : kBNB[l] - 4 * p; }
+constexpr unsigned bwd_layer_floats(int l) { return (unsigned)kBT[l] * 64u * (unsigned)kBNB[l]; }
+constexpr unsigned bwd_layer_offset(int l) { unsigned o = 0; for (int i = 0; i < l; ++i) o += bwd_layer_floats(i); return o; }
+constexpr unsigned bwd_pass_offset(int l, int p) { return bwd_layer_offset(l) + (unsigned)kBT[l] * 64u * 4u * (unsigned)p; }
+// auxiliary per-sample values of the forward pass the backward needs besides X: row 2 k + h holds lane half h's value of quantity k
+enum AuxRow {
+    AUX_G0 = 0,      // 3: gates of GeoVisFusion scale 0 (a0, a1, a2)
+    AUX_G1 = 3,      // 3: scale 1
+    AUX_TEX = 6,     // 4: TexVisFusion gates as the lane half uses them (gq, g11, ggf, glat)
+    AUX_PW = 10,     // pixel weight
+    AUX_XV = 11,     // 32: output of mlp_geo.layers1 before pooling, D registers [2 blocks][16]
+    AUX_LAT = 43,    // 12: ibr_compress output (the latent before its gate)
+    AUX_COUNT = 55
+};
+constexpr int AUX_ROWS = 2 * AUX_COUNT;
+// input gradients handed back to the host (gathers' backward): rows 2 t + h of
+constexpr int IG_GEO0 = 0;            // 96 slots: d [pix32 | nn32 | tw32] of scale 0 (channel = 32 h + t inside each group)
+constexpr int IG_GEO1 = 2 * 96;       // 12 slots: d [pix4 | nn4 | tw4] of scale 1
+constexpr int IG_TEX = IG_GEO1 + 24;  // 35 slots: d [vertex row 29 (h0 nearest, h1 twin) | query feature 6 (h0 q0..5, h1 q6..10)]
+constexpr int IG_ROWS = IG_TEX + 70;
+
 } // namespace vanerf

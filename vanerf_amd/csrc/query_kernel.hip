@@ -16,10 +16,11 @@
 #include <utility>
 
 #include "common.h"
+#include "mfma_chain.h"
 
 using namespace vanerf;
+using namespace vanerf_chain;
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
 
@@ -80,93 +81,9 @@ struct QueryParams {
     unsigned* queue;            // work-queue head: next unclaimed 32-sample group (zero before the launch)
     unsigned long long* short_groups; // optional: += number of groups that took the all-invalid short path
     float wm1[4], hm1[4];             // (float)(W - 1), (float)(H - 1) of the image / tex / geo0 / geo1 maps (kept scalar: no per-lane copies)
+    float *xs, *aux;                  // spill mode (training): X and auxiliary spills, [rows][npad] floats (layer_spec.h)
+    long long npad;
 };
-
-// ---------------------------------------------------------------------------------------------
-// weight fragment stream: register ring, prefetch distance ~1000 cycles
-// ---------------------------------------------------------------------------------------------
-template <int NB> struct WFrag { float v[NB]; };
-
-// Address = wave-uniform base (SGPR pair) + per-lane element offset (one VGPR): `global_load ... v_off, s[base] offset:imm`.
-// A per-lane 64-bit pointer would cost two VGPRs per 4 KB window of the unrolled stream.
-// A fragments are fetched with buffer loads: `buffer_load_dword{,x2,x3,x4} v, v_off, s[rsrc:rsrc+3], s_off offen`.  The 128-bit
-// resource descriptor and the per-step byte offset `so` (a compile-time constant -> one s_mov) are scalar, the lane's byte
-// offset `vb` (lane * NB * 4) is the only VGPR of address for the whole 640 KB stream: no VALU address arithmetic at all
-// (64-bit global addressing cost two v_add_co per 4 KB window here; VALU cycles add to fp32-MFMA cycles on gfx950).
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-typedef unsigned u32x3 __attribute__((ext_vector_type(3)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-using WRsrc = __amdgpu_buffer_rsrc_t;
-
-template <int NB> __device__ __forceinline__ WFrag<NB> wload(WRsrc rs, unsigned so, unsigned vb)
-{
-    WFrag<NB> r;
-    if constexpr (NB == 1) {
-        r.v[0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, vb, so, 0));
-    } else if constexpr (NB == 2) {
-        const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rs, vb, so, 0);
-        r.v[0] = __uint_as_float(t.x); r.v[1] = __uint_as_float(t.y);
-    } else if constexpr (NB == 3) {
-        const u32x3 t = __builtin_amdgcn_raw_buffer_load_b96(rs, vb, so, 0);
-        r.v[0] = __uint_as_float(t.x); r.v[1] = __uint_as_float(t.y); r.v[2] = __uint_as_float(t.z);
-    } else {
-        const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs, vb, so, 0);
-        r.v[0] = __uint_as_float(t.x); r.v[1] = __uint_as_float(t.y); r.v[2] = __uint_as_float(t.z); r.v[3] = __uint_as_float(t.w);
-    }
-    return r;
-}
-
-template <class F, int... I> __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>)
-{
-    (f(std::integral_constant<int, I>{}), ...);
-}
-template <int N, class F> __device__ __forceinline__ void static_for(F&& f)
-{
-    static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
-}
-
-// ring depth per block count: D * NB = 15..16 VGPRs, D * NB MFMAs (x 64 cycles) between a load and its use
-template <int NB> struct RingDepth { static constexpr int value = NB == 1 ? 16 : NB == 2 ? 8 : NB == 3 ? 5 : 4; };
-
-template <int NB> __device__ __forceinline__ void mfma_step(f32x16 (&acc)[NB], const WFrag<NB>& a, float b)
-{
-#pragma unroll
-    for (int ob = 0; ob < NB; ++ob) acc[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[ob], b, acc[ob], 0, 0, 0);
-#ifdef VANERF_PIN_KSTEPS // experiment knob: forbid scheduling across k-steps
-    __builtin_amdgcn_sched_barrier(0);
-#endif
-}
-
-// The register ring of one layer's A fragments.  ring_start() issues the first D loads; it is called well before the layer
-// runs (ahead of the previous layer's activation epilogue) so that the L2 latency of the ring fill is hidden.
-template <int NB> struct Ring { WFrag<NB> f[RingDepth<NB>::value]; };
-
-template <int NB, int T> __device__ __forceinline__ Ring<NB> ring_start(WRsrc rs, unsigned sbase, unsigned voff)
-{
-    constexpr int D = RingDepth<NB>::value;
-    Ring<NB> r;
-    static_for<D>([&](auto ic) {
-        constexpr int i = decltype(ic)::value;
-        if constexpr (i < T) r.f[i] = wload<NB>(rs, (sbase + i * 64 * NB) * 4u, voff);
-    });
-    return r;
-}
-
-// Runs the T k-steps of one layer, fully unrolled.  operand(integral_constant<int, t>) returns the B operand (this
-// lane's activation) of step t; step t's A fragment lives in ring slot t % D and is re-loaded with step t + D as soon
-// as it has been consumed.  `sbase` is the float offset of step 0 in the stream, `voff` = lane * NB * 4 (bytes).
-template <int NB, int T, class Op>
-__device__ __forceinline__ void run_layer(f32x16 (&acc)[NB], Ring<NB>& ring, WRsrc rs, unsigned sbase, unsigned voff, Op&& operand)
-{
-    constexpr int D = RingDepth<NB>::value;
-    static_for<T>([&](auto tc) {
-        constexpr int t = decltype(tc)::value;
-        const float b = operand(tc);
-        const WFrag<NB> a = ring.f[t % D];
-        if constexpr (t + D < T) ring.f[t % D] = wload<NB>(rs, (sbase + (t + D) * 64 * NB) * 4u, voff);
-        mfma_step<NB>(acc, a, b);
-    });
-}
 
 // ---------------------------------------------------------------------------------------------
 // split-bf16 ("bf16x3") variant of the layer runner: W = W_hi + W_lo, X = X_hi + X_lo (bf16 each),
@@ -447,18 +364,40 @@ template <int MODE, int NB> struct RingSel { using type = Ring<NB>; };
 template <int NB> struct RingSel<1, NB> { using type = RingB<NB>; };
 
 // `la`: the lane's place in a fragment -- its index (fp32 kernel) or its LDS / buffer byte offsets (split-bf16 kernel, LAddr)
-template <int MODE> struct LaneSel { using type = int; };
+// fp32 kernel: the lane index, plus (training, spill mode: vanerf_query_forward_spill) where this lane's column of the X / auxiliary
+// spills starts -- null pointers in the inference kernel, where every store below folds away
+struct LLane {
+    int lane;
+    float* xs;        // Xs + sample column + h * npad   (row r of the lane half: xs[(size_t)2 r * npad])
+    float* aux;       // the same into the auxiliary spill
+    long long npad;
+};
+template <int L, int t> __device__ __forceinline__ void spill_x(const LLane& la, float v)
+{
+    if (la.xs) la.xs[(size_t)(x_row_base(L) + 2 * t) * (size_t)la.npad] = v;
+}
+template <int K> __device__ __forceinline__ void spill_aux(const LLane& la, float v)
+{
+    if (la.aux) la.aux[(size_t)(2 * K) * (size_t)la.npad] = v;
+}
+template <int MODE> struct LaneSel { using type = LLane; };
 template <> struct LaneSel<1> { using type = LAddr; };
+__device__ __forceinline__ unsigned lane_of(const LLane& la) { return (unsigned)la.lane; }
 template <int MODE, int NB, int T, int L> __device__ __forceinline__ typename RingSel<MODE, NB>::type ring_start_m(WRsrc rs, const typename LaneSel<MODE>::type& la)
 {
-    if constexpr (MODE == 0) return ring_start<NB, T>(rs, layer_offset(L), (unsigned)la * NB * 4u);
+    if constexpr (MODE == 0) return ring_start<NB, T>(rs, layer_offset(L), lane_of(la) * NB * 4u);
     else return ring_start_b<NB, T, (L >= LDS_FIRST), layer_offset_b(L)>(rs, la);
 }
 
 template <int MODE, int NB, int T, int L, class Op>
 __device__ __forceinline__ void run_layer_m(f32x16 (&acc)[NB], typename RingSel<MODE, NB>::type& ring, WRsrc rs, const typename LaneSel<MODE>::type& la, Op&& operand)
 {
-    if constexpr (MODE == 0) run_layer<NB, T>(acc, ring, rs, layer_offset(L), (unsigned)la * NB * 4u, static_cast<Op&&>(operand));
+    if constexpr (MODE == 0)
+        run_layer<NB, T>(acc, ring, rs, layer_offset(L), lane_of(la) * NB * 4u, [&](auto tc) -> float {
+            const float b = operand(tc);
+            spill_x<L, decltype(tc)::value>(la, b); // (spill mode only)
+            return b;
+        });
     else run_layer_b<NB, T, (L >= LDS_FIRST), layer_offset_b(L), (((VANERF_P1_MASK >> L) & 1) ? 1 : ((VANERF_P2_MASK >> L) & 1) ? 2 : 3)>(acc, ring, rs, la, static_cast<Op&&>(operand));
 }
 
@@ -470,13 +409,6 @@ __device__ __forceinline__ int lane_id_fresh()
     return l;
 }
 
-template <int NB> __device__ __forceinline__ void zero(f32x16 (&acc)[NB])
-{
-#pragma unroll
-    for (int ob = 0; ob < NB; ++ob)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[ob][r] = 0.0f;
-}
 
 // Barriers of the block's four waves.  block_barrier_lds: LDS writes before it are visible after it (s_waitcnt lgkmcnt(0) + s_barrier; NOT
 // __syncthreads(), whose workgroup-scope release also drains vmcnt -- the fragment prefetch and the stores of the previous group are in flight here).
@@ -645,6 +577,7 @@ __device__ __forceinline__ void geo_scale(WRsrc W, int lane, const typename Lane
     const float a0 = __shfl(sigmoid_f(gate[0][0]), lane & 31);
     const float a1 = __shfl(sigmoid_f(gate[0][1]), lane & 31);
     const float a2 = __shfl(sigmoid_f(gate[0][2]), lane & 31);
+    if constexpr (MODE == 0) { constexpr int A = HC == 32 ? AUX_G0 : AUX_G1; spill_aux<A>(la, a0); spill_aux<A + 1>(la, a1); spill_aux<A + 2>(la, a2); }
 #pragma unroll
     for (int t = 0; t < HC; ++t) { pix[t] *= a0; nn[t] *= a1; tw[t] *= a2; }
     f32x16 mid[NBO];
@@ -657,9 +590,10 @@ __device__ __forceinline__ void geo_scale(WRsrc W, int lane, const typename Lane
                          [&](auto tc) -> float { constexpr int t = decltype(tc)::value; return lazy_act<MODE, ACT_RELU>(mid[t / 16][t % 16]); });
 }
 
-template <int MODE>
-__global__ __launch_bounds__(64 * WPB<MODE>, MODE == 1 ? VANERF_WAVES_PER_SIMD_B : VANERF_WAVES_PER_SIMD) void query_kernel(const QueryParams P)
+template <int MODE, bool SPILL = false>
+__global__ __launch_bounds__(64 * WPB<MODE>, MODE == 1 ? VANERF_WAVES_PER_SIMD_B : (SPILL ? 1 : VANERF_WAVES_PER_SIMD)) void query_kernel(const QueryParams P)
 {
+    static_assert(!SPILL || MODE == 0, "the training spill runs on the fp32 kernel");
     constexpr int WAVES_PER_BLOCK = WPB<MODE>, BLOCK = 64 * WAVES_PER_BLOCK;
 
     const int lane_k = threadIdx.x & 63;
@@ -741,7 +675,13 @@ __global__ __launch_bounds__(64 * WPB<MODE>, MODE == 1 ? VANERF_WAVES_PER_SIMD_B
         typename LaneSel<MODE>::type la;
         [[maybe_unused]] unsigned kp_lds = 0;
         if constexpr (MODE == 1) { la = make_laddr(lane, wv_u); kp_lds = LDS_KPT + ((la.w[0] >> 9) & 1u) * (PE_KPT_PER_HALF * 16u); }
-        else la = lane;
+        else {
+            la.lane = lane; la.xs = nullptr; la.aux = nullptr; la.npad = 0;
+            if (SPILL && g < ngroups) { // column = the slot's own place g * 32 + j (also for lanes beyond n: their output gradient is zero)
+                const size_t col = (size_t)g * 32 + (size_t)j + (size_t)h * (size_t)P.npad;
+                la.xs = P.xs + col; la.aux = P.aux + col; la.npad = P.npad;
+            }
+        }
         const long long s_raw = g * 32 + j;
         const bool live = s_raw < P.n;
         long long s = live ? s_raw : P.n - 1;
@@ -761,7 +701,7 @@ __global__ __launch_bounds__(64 * WPB<MODE>, MODE == 1 ? VANERF_WAVES_PER_SIMD_B
         unsigned anyv = 0;
 #pragma unroll
         for (int k = 0; k < WAVES_PER_BLOCK; ++k) anyv |= s_valid(par, k);
-        const bool any_valid = __builtin_amdgcn_readfirstlane((int)anyv) != 0;
+        const bool any_valid = SPILL || __builtin_amdgcn_readfirstlane((int)anyv) != 0; // (spill mode: every group writes every row)
         par ^= 1u;
         if (threadIdx.x == 0) pending = atomicAdd(P.queue, (unsigned)WAVES_PER_BLOCK);
         in_next = fetch(base_next + wv, j);
@@ -777,6 +717,7 @@ __global__ __launch_bounds__(64 * WPB<MODE>, MODE == 1 ? VANERF_WAVES_PER_SIMD_B
             float p = (wx * wy) * wz * mask;
             pw = p / (p + 1e-6f);
         }
+        if constexpr (MODE == 0) spill_aux<AUX_PW>(la, pw);
 
         STAMP(0); // front end
         // ---- 1-NN vertex (src/networks.py:27-33): found by vanerf_mesh_query_accel (same pass as the SDF) ----------
@@ -904,6 +845,7 @@ __global__ __launch_bounds__(64 * WPB<MODE>, MODE == 1 ? VANERF_WAVES_PER_SIMD_B
                                 const WFrag<4> a = ring0[f];
                                 // step 7(i+1)+f; after the last key point these are the first steps of the chain part below
                                 ring0[f] = wload<4>(W, (base0 + ((i + 1) * D0 + f) * 256) * 4u, v4);
+                                spill_x<L_MLP0, i * D0 + f>(la, feat[f]);
                                 mfma_step<4>(a0, a, feat[f]);
                             });
                         });
@@ -915,6 +857,7 @@ __global__ __launch_bounds__(64 * WPB<MODE>, MODE == 1 ? VANERF_WAVES_PER_SIMD_B
                             const float b = chain(g64, tc, std::integral_constant<int, 32>{});
                             const WFrag<4> a = ring0[t % D0];
                             if constexpr (t + D0 < TREM) ring0[t % D0] = wload<4>(W, (nextp + t * 256) * 4u, v4);
+                            spill_x<L_MLP0, PE_KPT_PER_HALF * D0 + t>(la, b);
                             mfma_step<4>(a0, a, b);
                         });
                     } else {
@@ -962,6 +905,8 @@ __global__ __launch_bounds__(64 * WPB<MODE>, MODE == 1 ? VANERF_WAVES_PER_SIMD_B
             if constexpr (!(MODE == 1 && W2)) tex_gathers();
             // ---- PoolModule mean/var over V = 1 views (src/utils.py:744-779, 854-880) --------------------------
             auto rh0 = ring_start_m<MODE, 2, 65, L_HEAD0>(W, la);
+            if constexpr (MODE == 0)
+                static_for<32>([&](auto rc) { constexpr int r = decltype(rc)::value; spill_aux<AUX_XV + r>(la, xv[r / 16][r % 16]); });
     #pragma unroll
             for (int b = 0; b < 2; ++b)
     #pragma unroll
@@ -1034,6 +979,10 @@ __global__ __launch_bounds__(64 * WPB<MODE>, MODE == 1 ? VANERF_WAVES_PER_SIMD_B
             const float g11 = h ? o2 : m1;    // gate 1 (nearest) / gate 2 (twin): [img3|tex8]
             const float ggf = h ? m0 : m3;    // gate 3 (nearest) / gate 4 (twin): global feature
             const float glat = h ? m1 : o1;   // gate 5: compressed latent
+            if constexpr (MODE == 0) {
+                spill_aux<AUX_TEX>(la, gq); spill_aux<AUX_TEX + 1>(la, g11); spill_aux<AUX_TEX + 2>(la, ggf); spill_aux<AUX_TEX + 3>(la, glat);
+                static_for<12>([&](auto rc) { constexpr int r = decltype(rc)::value; spill_aux<AUX_LAT + r>(la, lat[0][r]); });
+            }
 #pragma unroll
             for (int t = 0; t < 11; ++t) row[t] *= g11;
 #pragma unroll
@@ -1097,6 +1046,7 @@ extern "C" int vanerf_query_samples(const VanerfWeights* w, const VanerfFrame* f
         QueryParams P;
         P.f = f; P.w = w->dev; P.wbytes = (unsigned)(w->n_floats * sizeof(float)); P.pts = pts; P.qsdf = query_sdf; P.qvis = query_vis; P.noise = noise; P.knn_in = knn_idx; P.order = order; P.raw = raw;
         P.n = n; P.out = out; P.valid = valid; P.stamps = nullptr; P.short_groups = w->stats;
+        P.xs = nullptr; P.aux = nullptr; P.npad = 0;
         { const int ws[4] = {P.f.wi, P.f.wt, P.f.w0, P.f.w1}, hs[4] = {P.f.hi, P.f.ht, P.f.h0, P.f.h1};
           for (int i = 0; i < 4; ++i) { P.wm1[i] = (float)(ws[i] - 1); P.hm1[i] = (float)(hs[i] - 1); } }
        
@@ -1120,6 +1070,40 @@ extern "C" int vanerf_query_samples(const VanerfWeights* w, const VanerfFrame* f
             HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(query_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DYN_LDS_BYTES));
             hipLaunchKernelGGL(query_kernel<1>, dim3((unsigned)blocks), dim3(64 * WPB<1>), DYN_LDS_BYTES, (hipStream_t)stream, P);
         } else hipLaunchKernelGGL(query_kernel<0>, dim3((unsigned)blocks), dim3(64 * WPB<0>), 0, (hipStream_t)stream, P);
+        HIP_CHECK(hipGetLastError());
+    });
+}
+
+// Training: the fp32 kernel in spill mode -- the same forward pass of N samples (raw outputs [sdf_pred, rad, r, g, b]),
+// which also writes every layer's operands and a few auxiliary values for the fused backward chain (query_backward.hip); layouts in layer_spec.h.
+extern "C" int vanerf_query_forward_spill(const VanerfWeights* w, const VanerfFrame* frame, const float* pts, const float* query_sdf,
+                                          const uint8_t* query_vis, const int32_t* knn_idx, int64_t n, int64_t npad, float* out_raw, uint8_t* valid,
+                                          float* xs, float* aux, void* queue_word, void* stream)
+{
+    return guarded([&] {
+        if (n <= 0) throw_error("vanerf_query_forward_spill: n = %lld", (long long)n);
+        if (!w || !w->dev || w->mode != 0) throw_error("vanerf_query_forward_spill: needs an fp32 weight handle (vanerf_weights_pack mode 0)");
+        if (!frame || !pts || !query_sdf || !query_vis || !knn_idx || !out_raw || !xs || !aux) throw_error("vanerf_query_forward_spill: null argument");
+        if (!queue_word || (reinterpret_cast<uintptr_t>(queue_word) & 7u)) throw_error("vanerf_query_forward_spill: queue_word must be 8 bytes of device memory, 8-byte aligned");
+        if (npad < n || npad % 32 != 0) throw_error("vanerf_query_forward_spill: npad = %lld must be a multiple of 32 and >= n = %lld", (long long)npad, (long long)n);
+        const VanerfFrame& f = *frame;
+        if (!f.geo0 || !f.geo1 || !f.tex || !f.img || !f.mask || !f.verts || !f.vfeat0 || !f.vfeat1 || !f.vfeat_tex || !f.vert_vis || !f.kpt_cam)
+            throw_error("vanerf_query_forward_spill: frame has a null pointer");
+        QueryParams P;
+        P.f = f; P.w = w->dev; P.wbytes = (unsigned)(w->n_floats * sizeof(float)); P.pts = pts; P.qsdf = query_sdf; P.qvis = query_vis; P.noise = nullptr; P.knn_in = knn_idx; P.order = nullptr; P.raw = 1;
+        P.n = n; P.out = out_raw; P.valid = valid; P.stamps = nullptr; P.short_groups = nullptr;
+        P.xs = xs; P.aux = aux; P.npad = npad;
+        { const int ws[4] = {P.f.wi, P.f.wt, P.f.w0, P.f.w1}, hs[4] = {P.f.hi, P.f.ht, P.f.h0, P.f.h1};
+          for (int i = 0; i < 4; ++i) { P.wm1[i] = (float)(ws[i] - 1); P.hm1[i] = (float)(hs[i] - 1); } }
+        const long long ngroups = (n + 31) / 32;
+        long long blocks = (ngroups + WPB<0> - 1) / WPB<0>;
+        int dev = 0, cus = 256;
+        HIP_CHECK(hipGetDevice(&dev));
+        HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        if (blocks > cus) blocks = cus; // one 4-wave block per CU (the spill build takes the whole register file)
+        P.queue = static_cast<unsigned*>(queue_word);
+        HIP_CHECK(hipMemsetAsync(P.queue, 0, 8, (hipStream_t)stream));
+        hipLaunchKernelGGL((query_kernel<0, true>), dim3((unsigned)blocks), dim3(64 * WPB<0>), 0, (hipStream_t)stream, P);
         HIP_CHECK(hipGetLastError());
     });
 }

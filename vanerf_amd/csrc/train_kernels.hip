@@ -5,6 +5,8 @@
 // training step and the tables have 1e3..1.6e4 rows: as global atomics (torch's index_add_) every row is hit by hundreds of samples and
 // the step spent 20 ms (28 %) there.  Here a block keeps a slice of the table's channels in LDS, adds its share of the samples with LDS
 // atomics (a contended LDS atomic costs cycles, not a trip to the memory side), and flushes the slice once with global atomics.
+#include <algorithm>
+
 #include "common.h"
 
 using namespace vanerf;
@@ -58,7 +60,11 @@ extern "C" int vanerf_scatter_add_rows(const int32_t* idx, const float* w, const
         while (cs > 1 && ((size_t)R * cs * 4 > 128 * 1024 || cs / 2 >= C)) cs /= 2;
         if ((size_t)R * cs * 4 > 128 * 1024) throw_error("vanerf_scatter_add_rows: a table of %d rows does not fit the LDS slice", R);
         const int slices = (C + cs - 1) / cs;
+        // blocks = chunks x slices: 4 096 samples per chunk for a whole training patch (~5e5 samples), but never fewer than ~512 blocks' worth of
+        // work in flight -- the fused backward calls this once per block of 65 536 samples, where 16 chunks x 4 slices left three quarters of the chip idle
         int chunks = (int)((n + 4095) / 4096);
+        const int fill = (int)std::min<long long>((n + 511) / 512, 512 / slices > 0 ? 512 / slices : 1);
+        if (chunks < fill) chunks = fill;
         if (chunks > 1024 / slices) chunks = 1024 / slices > 0 ? 1024 / slices : 1;
         if (chunks < 1) chunks = 1;
         const size_t lds = (size_t)R * cs * 4;

@@ -154,66 +154,131 @@ Pairs tex_input_pairs()
 
 } // namespace
 
+namespace {
+
+// k-pairs (input channel of lane half 0 / 1 per k-step) of every layer: structure only, no weights
+Pairs layer_pairs(int l)
+{
+    Pairs p;
+    switch (l) {
+    case L_GEO_AT0_A: case L_GEO_ATED0_A: return geo_input_pairs(64);
+    case L_GEO_AT1_A: case L_GEO_ATED1_A: return geo_input_pairs(8);
+    case L_GEO_AT0_B: case L_GEO_AT1_B: chain(p, 1, 6, 0, 10); return p;
+    case L_GEO_ATED0_B: chain(p, 2, 16, 0, 64); return p;
+    case L_GEO_ATED1_B: chain(p, 1, 4, 0, 8); return p;
+    case L_MLP0:
+        for (int i = 0; i < PE_KPT_PER_HALF; ++i)
+            for (int f = 0; f < PE_FEATS; ++f) p.emplace_back(f * 42 + i, f * 42 + PE_KPT_PER_HALF + i);
+        chain(p, 2, 16, 294, 64);
+        bias_pair(p);
+        return p;
+    case L_MLP1: chain(p, 4, 16, 0, 128); bias_pair(p); return p;
+    case L_MLP2: chain(p, 4, 16, 0, 128); chain(p, 1, 4, 128, 8); bias_pair(p); return p;
+    case L_MLP3: chain(p, 4, 12, 0, 120); bias_pair(p); return p;
+    case L_HEAD0: case L_IBR: chain(p, 2, 16, 0, 64); chain(p, 2, 16, 64, 64); bias_pair(p); return p; // [mean | var]
+    case L_HEAD1: case L_HEAD2: chain(p, 2, 16, 0, 64); bias_pair(p); return p;
+    case L_TEX_AT_A: case L_TEX_A: return tex_input_pairs();
+    case L_TEX_AT_B: case L_TEX_B: chain(p, 3, 16, 0, 96); return p;
+    }
+    throw_error("internal: no layer %d", l);
+}
+
+// effective [out][in] matrix (+ bias) of every layer (weight-norm folded)
+Mat layer_matrix(const VanerfWeightTable& w, int l)
+{
+    switch (l) {
+    case L_GEO_AT0_A: return plain(w.geo_at0_w1, nullptr, 10, 196);
+    case L_GEO_AT0_B: return plain(w.geo_at0_w2, nullptr, 3, 10);
+    case L_GEO_ATED0_A: return plain(w.geo_ated0_w1, nullptr, 64, 196);
+    case L_GEO_ATED0_B: return plain(w.geo_ated0_w2, nullptr, 64, 64);
+    case L_GEO_AT1_A: return plain(w.geo_at1_w1, nullptr, 10, 28);
+    case L_GEO_AT1_B: return plain(w.geo_at1_w2, nullptr, 3, 10);
+    case L_GEO_ATED1_A: return plain(w.geo_ated1_w1, nullptr, 8, 28);
+    case L_GEO_ATED1_B: return plain(w.geo_ated1_w2, nullptr, 8, 8);
+    case L_MLP0: return weight_normed(w.l1_v[0], w.l1_g[0], w.l1_b[0], 128, 358);
+    case L_MLP1: return weight_normed(w.l1_v[1], w.l1_g[1], w.l1_b[1], 128, 128);
+    case L_MLP2: return weight_normed(w.l1_v[2], w.l1_g[2], w.l1_b[2], 120, 136);
+    case L_MLP3: return plain(w.l1_w3, w.l1_b3, 64, 120);
+    case L_HEAD0: return weight_normed(w.l2_v[0], w.l2_g[0], w.l2_b[0], 64, 128);
+    case L_HEAD1: return weight_normed(w.l2_v[1], w.l2_g[1], w.l2_b[1], 64, 64);
+    case L_HEAD2: return plain(w.l2_w2, w.l2_b2, 2, 64);
+    case L_IBR: return plain(w.ibr_w, w.ibr_b, 24, 128);
+    case L_TEX_AT_A: return plain(w.tex_at_w1, nullptr, 96, 96);
+    case L_TEX_AT_B: return plain(w.tex_at_w2, nullptr, 6, 96);
+    case L_TEX_A: return plain(w.tex_w1, nullptr, 96, 96);
+    // IBRRenderingHead at V = 1 returns rgb_feat[..., :3] exactly (src/model.py:1613, 1635): rows 0..2 of 40
+    case L_TEX_B: return plain(w.tex_w2, nullptr, 3, 96);
+    }
+    throw_error("internal: no layer %d", l);
+}
+
+// Backward stream of one layer (layer_spec.h): dX = W^T dY as the same MFMA chain with the roles swapped.  K dimension: the layer's output
+// rows in D-register order (k-pair t'' = block t''/16, register t''%16: rows 32 ob + row0(r) and + 4); output rows: the layer's input
+// SLOTS -- slot row 32 ib + jj of the result is k-pair t = 16 (kBLO + ib) + reg', lane half h' with jj = row0(reg') + 4 h', i.e. exactly
+// where the previous layer's D registers sit, so the gradient chains from layer to layer in registers as the activations do forwards.
+void emit_bwd(std::vector<float>& out, int layer, const Mat& m, const Pairs& pairs)
+{
+    const int T = kT[layer], BT = kBT[layer], nbt = kBNB[layer], blo = kBLO[layer];
+    if (m.nout != kNOUT[layer]) throw_error("internal: layer %d has %d outputs, spec says %d", layer, m.nout, kNOUT[layer]);
+    Pairs kk; // output rows per k-pair, D-register order
+    chain(kk, (m.nout + 31) / 32, 16, 0, m.nout);
+    for (int t = BT; t < (int)kk.size(); ++t)
+        if (kk[t].first != ZERO || kk[t].second != ZERO) throw_error("internal: layer %d: output row beyond its %d backward k-pairs", layer, BT);
+    const size_t base = out.size();
+    if (base != bwd_layer_offset(layer)) throw_error("internal: backward stream of layer %d starts at %zu, spec says %u", layer, base, bwd_layer_offset(layer));
+    out.resize(base + bwd_layer_floats(layer), 0.0f);
+    for (int p = 0; 4 * p < nbt; ++p) {
+        const int nb = bwd_pass_blocks(layer, p);
+        float* dst = out.data() + bwd_pass_offset(layer, p);
+        for (int t2 = 0; t2 < BT; ++t2)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int o = (lane >> 5) ? kk[t2].second : kk[t2].first;
+                if (o == ZERO) continue;
+                const int jj = lane & 31, hs = (jj >> 2) & 1, reg = (jj & 3) + 4 * (jj >> 3);
+                for (int ib = 0; ib < nb; ++ib) {
+                    const int t = 16 * (blo + 4 * p + ib) + reg;
+                    if (t >= T) continue;
+                    const int c = hs ? pairs[t].second : pairs[t].first;
+                    if (c < 0) continue; // ZERO / BIAS slots carry no input gradient
+                    dst[((size_t)t2 * 64 + lane) * nb + ib] = m.w[(size_t)o * m.kin + c];
+                }
+            }
+    }
+}
+
+} // namespace
+
 namespace vanerf {
 
-void pack_weights_host(const VanerfWeightTable& w, std::vector<float>& out, LayerOffsets& offs, int mode)
+void pack_weights_host(const VanerfWeightTable& w, std::vector<float>& out, LayerOffsets& offs, int mode, std::vector<float>* bwd)
 {
     out.clear();
-    auto begin = [&](int l) {
+    if (bwd) bwd->clear();
+    for (int l = 0; l < NUM_LAYERS; ++l) {
         offs.off[l] = (unsigned)out.size();
         const unsigned want = mode ? layer_offset_b(l) : layer_offset(l);
         if (offs.off[l] != want) throw_error("internal: layer %d starts at %u, layer_spec.h says %u", l, offs.off[l], want);
-    };
-    auto put = [&](std::vector<float>& o, int l, const Mat& m, const Pairs& p) { mode ? emit_b(o, l, m, p) : emit(o, l, m, p); };
-
-    // ---- GeoVisFusion (src/networks.py:75-106) ------------------------------------------------
-    {
-        Pairs in0 = geo_input_pairs(64), in1 = geo_input_pairs(8), b10, c2, c1;
-        chain(b10, 1, 6, 0, 10);
-        chain(c2, 2, 16, 0, 64);
-        chain(c1, 1, 4, 0, 8);
-        begin(L_GEO_AT0_A);   put(out, L_GEO_AT0_A, plain(w.geo_at0_w1, nullptr, 10, 196), in0);
-        begin(L_GEO_AT0_B);   put(out, L_GEO_AT0_B, plain(w.geo_at0_w2, nullptr, 3, 10), b10);
-        begin(L_GEO_ATED0_A); put(out, L_GEO_ATED0_A, plain(w.geo_ated0_w1, nullptr, 64, 196), in0);
-        begin(L_GEO_ATED0_B); put(out, L_GEO_ATED0_B, plain(w.geo_ated0_w2, nullptr, 64, 64), c2);
-        begin(L_GEO_AT1_A);   put(out, L_GEO_AT1_A, plain(w.geo_at1_w1, nullptr, 10, 28), in1);
-        begin(L_GEO_AT1_B);   put(out, L_GEO_AT1_B, plain(w.geo_at1_w2, nullptr, 3, 10), b10);
-        begin(L_GEO_ATED1_A); put(out, L_GEO_ATED1_A, plain(w.geo_ated1_w1, nullptr, 8, 28), in1);
-        begin(L_GEO_ATED1_B); put(out, L_GEO_ATED1_B, plain(w.geo_ated1_w2, nullptr, 8, 8), c1);
-    }
-    // ---- MLPUNetFusion (src/utils.py:633-649, 822-852) ------------------------------------------
-    {
-        Pairs p0;
-        for (int i = 0; i < PE_KPT_PER_HALF; ++i)
-            for (int f = 0; f < PE_FEATS; ++f) p0.emplace_back(f * 42 + i, f * 42 + PE_KPT_PER_HALF + i);
-        chain(p0, 2, 16, 294, 64);
-        bias_pair(p0);
-        begin(L_MLP0); put(out, L_MLP0, weight_normed(w.l1_v[0], w.l1_g[0], w.l1_b[0], 128, 358), p0);
-        Pairs p1; chain(p1, 4, 16, 0, 128); bias_pair(p1);
-        begin(L_MLP1); put(out, L_MLP1, weight_normed(w.l1_v[1], w.l1_g[1], w.l1_b[1], 128, 128), p1);
-        Pairs p2; chain(p2, 4, 16, 0, 128); chain(p2, 1, 4, 128, 8); bias_pair(p2);
-        begin(L_MLP2); put(out, L_MLP2, weight_normed(w.l1_v[2], w.l1_g[2], w.l1_b[2], 120, 136), p2);
-        Pairs p3; chain(p3, 4, 12, 0, 120); bias_pair(p3);
-        begin(L_MLP3); put(out, L_MLP3, plain(w.l1_w3, w.l1_b3, 64, 120), p3);
-        Pairs pool; chain(pool, 2, 16, 0, 64); chain(pool, 2, 16, 64, 64); bias_pair(pool); // [mean | var]
-        begin(L_HEAD0); put(out, L_HEAD0, weight_normed(w.l2_v[0], w.l2_g[0], w.l2_b[0], 64, 128), pool);
-        Pairs h1; chain(h1, 2, 16, 0, 64); bias_pair(h1);
-        begin(L_HEAD1); put(out, L_HEAD1, weight_normed(w.l2_v[1], w.l2_g[1], w.l2_b[1], 64, 64), h1);
-        begin(L_HEAD2); put(out, L_HEAD2, plain(w.l2_w2, w.l2_b2, 2, 64), h1);
-        begin(L_IBR);   put(out, L_IBR, plain(w.ibr_w, w.ibr_b, 24, 128), pool);
-    }
-    // ---- TexVisFusion per-sample part (src/networks.py:281-293) -----------------------------------
-    {
-        Pairs in = tex_input_pairs(), c3;
-        chain(c3, 3, 16, 0, 96);
-        begin(L_TEX_AT_A); put(out, L_TEX_AT_A, plain(w.tex_at_w1, nullptr, 96, 96), in);
-        begin(L_TEX_AT_B); put(out, L_TEX_AT_B, plain(w.tex_at_w2, nullptr, 6, 96), c3);
-        begin(L_TEX_A);    put(out, L_TEX_A, plain(w.tex_w1, nullptr, 96, 96), in);
-        // IBRRenderingHead at V = 1 returns rgb_feat[..., :3] exactly (src/model.py:1613, 1635): rows 0..2 of 40
-        begin(L_TEX_B);    put(out, L_TEX_B, plain(w.tex_w2, nullptr, 3, 96), c3);
+        const Mat m = layer_matrix(w, l);
+        const Pairs p = layer_pairs(l);
+        mode ? emit_b(out, l, m, p) : emit(out, l, m, p);
+        if (bwd) emit_bwd(*bwd, l, m, p);
     }
     // slack behind the last layer (prefetch rings never read past a layer's own steps, this is belt and braces)
     out.resize(out.size() + 2 * 64 * 4, 0.0f);
+    if (bwd) bwd->resize(bwd->size() + 2 * 64 * 4, 0.0f);
+}
+
+// slot -> input channel of layer l (2 T entries, slot 2 t + h): >= 0 channel of the reference's [out][in] matrix, -1 unused, -2 bias
+int layer_slots(int l, int* k_of_slot, int cap)
+{
+    if (l < 0 || l >= NUM_LAYERS) throw_error("vanerf_layer_slots: layer %d", l);
+    const Pairs p = layer_pairs(l);
+    if ((int)p.size() != kT[l]) throw_error("internal: layer %d has %d k-pairs, spec says %d", l, (int)p.size(), kT[l]);
+    if (k_of_slot) {
+        if (cap < 2 * kT[l]) throw_error("vanerf_layer_slots: room for %d slots, layer %d has %d", cap, l, 2 * kT[l]);
+        for (int t = 0; t < kT[l]; ++t) { k_of_slot[2 * t] = p[t].first; k_of_slot[2 * t + 1] = p[t].second; }
+    }
+    return 2 * kT[l];
 }
 
 } // namespace vanerf

@@ -278,8 +278,15 @@ class VANeRF(nn.Module):
     def _hot_state(self):
         return {k: v for k, v in self.state_dict().items() if not k.startswith(("geo_encoder.", "tex_encoder."))}
 
-    def packed_weights(self):
-        """MFMA-fragment copy of the per-sample weights, re-packed whenever a parameter changed (training steps, load_state_dict)."""
+    def packed_weights(self, precision=None):
+        """MFMA-fragment copy of the per-sample weights, re-packed whenever a parameter changed (training steps, load_state_dict).
+        precision: None = the module's own; "fp32" = the handle the fused backward runs on (it carries the transposed streams)."""
+        if precision is not None and precision != self.precision:
+            sd = self._hot_state()
+            key = (precision,) + tuple((k, v._version, v.data_ptr()) for k, v in sd.items())
+            if getattr(self, "_packed_alt", None) is None or self._packed_alt[0] != key:
+                self._packed_alt = (key, R.PackedWeights(sd, mode=precision))
+            return self._packed_alt[1]
         sd = self._hot_state()
         key = tuple((k, v._version, v.data_ptr()) for k, v in sd.items() if k.startswith(("geo_vis_fusion.", "mlp_geo.", "ibr_compress_gfeat.",
                                                                                          "tex_vis_fusion.fconv.", "tex_vis_fusion.fconv_at.", "sigmoid_beta")))
@@ -527,7 +534,11 @@ class VANeRF(nn.Module):
         spec = {"values": [out[k] for k in keys], "keys": keys, "names": names, "frame": frame, "pass": o, "sp_args": self.kwargs["sp_args"],
                 "rays_per_chunk": self.kwargs.get("grad_rays_per_chunk", G.GRAD_RAYS_PER_CHUNK),
                 "samples_per_block": self.kwargs.get("grad_samples_per_block", G.GRAD_SAMPLES_PER_BLOCK),
-                "graph_blocks": bool(self.kwargs.get("grad_graph_blocks", False))}
+                "graph_blocks": bool(self.kwargs.get("grad_graph_blocks", False)), "hip_backward": None}
+        if self.kwargs.get("hip_backward", True):
+            # the per-sample networks' gradient on the fused HIP backward (config key hip_backward, default on; off = the PyTorch graph of
+            # torch_graph.networks_at, which stays as the independent checker): fp32 weights of this step, the pass's per-frame tables
+            spec["hip_backward"] = {"w0": self.packed_weights("fp32"), "fdat": fd, "block": int(self.kwargs.get("hip_backward_block", 65536))}
         for k, v in zip(keys, G.PassGradient.apply(spec, *leaves)):
             out[k] = v
         return out

@@ -462,6 +462,7 @@ class PassGradient(torch.autograd.Function):
                     if g is not None:
                         total[i] = g if total[i] is None else total[i] + g
 
+            hip_state = None
             table_graph = texture_vertex_table(P, project_vertices(frame["verts"], frame["cam"]), frame["feat_tex"], frame["img"])
             table = table_graph.detach().requires_grad_(True)
             g_table = torch.zeros_like(table)
@@ -528,6 +529,25 @@ class PassGradient(torch.autograd.Function):
                 nz_a = None if cols["noise"][0] is None else cat("noise")
                 nz2_a, d2_a = (cat("noise2"), cat("d2")) if cf is not None else (None, None)
                 n_all = pts_a.shape[0]
+                if spec.get("hip_backward") is not None:
+                    # the fused HIP backward (csrc/query_backward.hip, hip_backward.py): two launches and twenty matrix products per block of samples
+                    from . import hip_backward as HB
+                    hb = spec["hip_backward"]
+                    if hip_state is None:  # the first chunk of rays is a full one: its sample count bounds every later block
+                        blk = min(int(hb["block"]), (n_all + 31) // 32 * 32)
+                        ws = HB.workspace(blk, pts_a.device)
+                        ws.dw.zero_()
+                        hip_state = {"ws": ws, "blk": blk, "scatter": HB.InputScatter(frame, pts_a.device)}
+                    ws, blk = hip_state["ws"], hip_state["blk"]
+                    with torch.no_grad():
+                        pts_a, qs_a, qv_a, knn_a = pts_a.contiguous(), qs_a.contiguous(), qv_a.contiguous(), knn_a.contiguous()
+                        hip_state["scatter"].prepare(project(pts_a, frame["cam"])[0], knn_a)
+                        for b0 in range(0, n_all, blk):
+                            sl = slice(b0, min(n_all, b0 + blk))
+                            ig, nb = HB.run_block(ws, hb["w0"], hb["fdat"], pts_a[sl], qs_a[sl], qv_a[sl], knn_a[sl], d_a[sl],
+                                                  None if nz_a is None else nz_a[sl], None if d2_a is None else d2_a[sl], None if nz2_a is None else nz2_a[sl])
+                            hip_state["scatter"].add(sl, HB.input_gradients(ig, nb))
+                    continue
                 block = spec.get("samples_per_block") or n_all
                 if spec.get("graph_blocks") and spec.get("samples_per_block"):
                     runner = _BlockGraph.get(list(ctx.saved_tensors), names, frame, table, block, nz2_a is not None, nz_a is not None, spec["sp_args"])
@@ -554,5 +574,17 @@ class PassGradient(torch.autograd.Function):
                     accumulate(g_block[:-1])
                     if g_block[-1] is not None:
                         g_table += g_block[-1]
+            if hip_state is not None:
+                from . import hip_backward as HB
+                sc = hip_state["scatter"]
+                by_name = dict(HB.parameter_gradients(hip_state["ws"], P))
+                by_name["@feat_geo0"], by_name["@feat_geo1"], by_name["@feat_tex"] = sc.map_gradient("map0"), sc.map_gradient("map1"), sc.map_gradient("tex")
+                accumulate([by_name.get(n) for n in names])
+                # the per-vertex tables are bilinear samples of the maps at the projected vertices (src/networks.py:86-87, 94-95): their gradient goes
+                # back through that gather (and table29's through the per-frame stacks below)
+                vert_xy = project_vertices(frame["verts"], frame["cam"])
+                tabs = [sample_map(frame["feat_geo"][0], vert_xy), sample_map(frame["feat_geo"][1], vert_xy)]
+                accumulate(torch.autograd.grad(tabs, loc, [sc.acc["vtab0"], sc.acc["vtab1"]], allow_unused=True))
+                g_table = g_table + sc.acc["table29"]
             accumulate(torch.autograd.grad(table_graph, loc, g_table, allow_unused=True))
         return (None, *total)
