@@ -285,6 +285,8 @@ int vanerf_render_pass(const VanerfWeights* w, const VanerfFrame* frame, const V
  * All device pointers, fp32 / int32; `table` is accumulated into.  Samples outnumber rows by hundreds: the adds go through LDS-resident
  * slices of the table instead of contended global atomics.                                                                               */
 int vanerf_scatter_add_rows(const int32_t* idx, const float* w, const float* g, int64_t n, int C, float* table, int R, void* stream);
+/* the same with FOUR (index, weight) pairs per sample, idx4 / w4 = [4][ld] (ld >= n): the backward of a bilinear tap gather (src/utils.py:136-151) */
+int vanerf_scatter_add_taps(const int32_t* idx4, const float* w4, int64_t ld, const float* g, int64_t n, int C, float* table, int R, void* stream);
 
 /* f-4, the fused backward pass of the per-sample networks (training; reference: autograd through VANeRF.query, src/model.py:748-957, driven by
  * training_step, src/model.py:381-459).  Two launches per block of n samples, on one stream, with an fp32 weight handle (vanerf_weights_pack mode 0):

@@ -121,25 +121,41 @@ def _weight_products_on(ws, xs, ys, npad):
         torch.baddbmm(a, g.view(lay["n_out"], S, per).transpose(0, 1), x.view(lay["n_slots"], S, per).permute(1, 2, 0), out=a)
 
 
+_SLOTS_ON = {}
+
+
+def _slot_tables(device):
+    """Per layer, on the device, once: (slots with a channel, their channels, the bias slot or None)."""
+    key = str(device)
+    if key not in _SLOTS_ON:
+        tabs = []
+        for lay in layout()["layers"]:
+            sl = lay["slots"]
+            cols = (sl >= 0).nonzero().view(-1)
+            bias = (sl == -2).nonzero().view(-1)
+            tabs.append((cols.to(device), sl[cols].to(device), int(bias[0]) if bias.numel() else None))
+        _SLOTS_ON[key] = tabs
+    return _SLOTS_ON[key]
+
+
 def parameter_gradients(ws, P):
     """The flat accumulator -> gradients of the reference's parameters (dict key -> tensor).  P: name -> leaf tensor."""
     L = layout()
     out = {}
-    for lay, spec in zip(L["layers"], LAYER_PARAMS):
-        dwp = ws.dw_l[L["layers"].index(lay)].sum(0)
-        slots = lay["slots"].to(dwp.device)
-        cols = (slots >= 0).nonzero().view(-1)
+    tabs = _slot_tables(ws.dw.device)
+    for li, (lay, spec) in enumerate(zip(L["layers"], LAYER_PARAMS)):
+        dwp = ws.dw_l[li].sum(0)
+        cols, chans, bias_slot = tabs[li]
         kind = spec[0]
         ref = P[spec[1]] if kind == "conv" else P[spec[1] + (".weight_v" if kind == "wn" else ".weight")]
         kin = ref.shape[1]
-        dw = torch.zeros(lay["n_out"], kin, dtype=torch.float32, device=dwp.device).index_add_(1, slots[cols], dwp[:, cols])
+        dw = torch.zeros(lay["n_out"], kin, dtype=torch.float32, device=dwp.device).index_add_(1, chans, dwp[:, cols])
         if kind == "conv":
             g = torch.zeros_like(ref)
             g[:lay["n_out"], :, 0] = dw  # (fconv.2 has 40 output channels, of which one view uses 3: src/model.py:1613, 1635)
             out[spec[1]] = g
             continue
-        bias = (slots == -2).nonzero().view(-1)
-        out[spec[1] + ".bias"] = dwp[:, bias[0]].clone()
+        out[spec[1] + ".bias"] = dwp[:, bias_slot].clone()
         if kind == "lin":
             out[spec[1] + ".weight"] = dw
         else:  # weight-norm fold W = v g / ||v||_row (src/utils.py:674-675), differentiated by autograd itself
@@ -185,8 +201,8 @@ def _taps(xy, H, W):
     wx, wy = x - x0, y - y0
     x0, y0 = x0.long(), y0.long()
     x1, y1 = (x0 + 1).clamp(max=W - 1), (y0 + 1).clamp(max=H - 1)
-    idx = torch.stack([y0 * W + x0, y0 * W + x1, y1 * W + x0, y1 * W + x1]).to(torch.int32)
-    w = torch.stack([(1.0 - wx) * (1.0 - wy), wx * (1.0 - wy), (1.0 - wx) * wy, wx * wy])
+    idx = torch.stack([y0 * W + x0, y0 * W + x1, y1 * W + x0, y1 * W + x1]).to(torch.int32).contiguous()
+    w = torch.stack([(1.0 - wx) * (1.0 - wy), wx * (1.0 - wy), (1.0 - wx) * wy, wx * wy]).contiguous()
     return idx, w
 
 
@@ -213,8 +229,7 @@ class InputScatter:
         """sl: the block's slice of the prepared samples; g: input_gradients() of the block."""
         for name, key in (("map0", "pix0"), ("map1", "pix1"), ("tex", "tex_xy")):
             idx, w = self.taps[name]
-            for k in range(4):
-                R.scatter_add_rows(self.acc[name], idx[k, sl], g[key], w[k, sl])
+            R.scatter_add_taps(self.acc[name], idx, w, sl, g[key])
         for name, kn, kt in (("vtab0", "nn0", "tw0"), ("vtab1", "nn1", "tw1"), ("table29", "row_nn", "row_tw")):
             R.scatter_add_rows(self.acc[name], self.knn[sl], g[kn], self.vn[sl])
             R.scatter_add_rows(self.acc[name], self.twin[sl], g[kt], self.vt[sl])

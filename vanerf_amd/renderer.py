@@ -691,6 +691,19 @@ def render_pass_c(weights, frame, cam_tar, bounds, x0, y0, step, nx, ny, sample_
     return out
 
 
+def scatter_add_taps(table, idx4, w4, sl, g):
+    """table[idx4[k][i]] += w4[k][i] * g[i - sl.start] for the samples i of slice `sl`, k < 4 (vanerf_scatter_add_taps): idx4 (4, N) int32, w4 (4, N)."""
+    n, C = g.shape
+    assert idx4.shape == w4.shape and idx4.shape[0] == 4 and idx4.is_contiguous() and w4.is_contiguous() and table.is_contiguous() and sl.stop - sl.start == n
+    if table.shape[0] * 4 > 128 * 1024:
+        for k in range(4):
+            table.index_add_(0, idx4[k, sl].long(), g * w4[k, sl].reshape(-1, 1))
+        return table
+    check(lib.vanerf_scatter_add_taps(ctypes.c_void_p(idx4.data_ptr() + 4 * sl.start), ctypes.c_void_p(w4.data_ptr() + 4 * sl.start), idx4.shape[1],
+                                      _ptr(g.contiguous(), torch.float32), n, C, _ptr(table, torch.float32), table.shape[0], _stream()))
+    return table
+
+
 def scatter_add_rows(table, idx, g, w=None):
     """table[idx[i]] += w[i] * g[i] (vanerf_scatter_add_rows): the backward of a row gather over ~1e6 samples into a table of ~1e3..1e4 rows."""
     n, C = g.shape

@@ -450,6 +450,14 @@ class PassGradient(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *gouts):
         spec, names = ctx.spec, ctx.spec["names"]
+        import os, time
+        marks = [] if os.environ.get("VANERF_TIME_BACKWARD") else None  # diagnostic: synchronised wall time per section (tools/perf_train_parts.py)
+
+        def mark(what):
+            if marks is not None:
+                torch.cuda.synchronize()
+                marks.append((what, time.perf_counter()))
+        mark("start")
         with torch.enable_grad():
             loc = [t.detach().requires_grad_(True) for t in ctx.saved_tensors]
             L = dict(zip(names, loc))
@@ -501,8 +509,10 @@ class PassGradient(torch.autograd.Function):
                     # images are (1,3,h,w) / (1,h,w) over the patch's rays in row-major order: the chunk's rays are a slice of the flattened image
                     gk = g.reshape(3, -1).t()[r0:r1] if k.startswith("tex_fg") else g.reshape(-1)[r0:r1]
                     pairs.append((outs[k], gk))
+                mark("table graph + composite forward")
                 grads = torch.autograd.grad([a for a, _ in pairs], per_sample + loc, [b for _, b in pairs], allow_unused=True)
                 accumulate(grads[len(per_sample):])
+                mark("composite backward")
                 del outs, pairs, col, dep, acc
                 # (2) the per-sample networks, one block of samples after the other (samples are independent): only one block's graph exists at a
                 #     time, which is what bounds the step's memory -- the coarse and the fine batch are never alive together
@@ -539,14 +549,17 @@ class PassGradient(torch.autograd.Function):
                         ws.dw.zero_()
                         hip_state = {"ws": ws, "blk": blk, "scatter": HB.InputScatter(frame, pts_a.device)}
                     ws, blk = hip_state["ws"], hip_state["blk"]
+                    mark("sample lists")
                     with torch.no_grad():
                         pts_a, qs_a, qv_a, knn_a = pts_a.contiguous(), qs_a.contiguous(), qv_a.contiguous(), knn_a.contiguous()
                         hip_state["scatter"].prepare(project(pts_a, frame["cam"])[0], knn_a)
+                        mark("taps")
                         for b0 in range(0, n_all, blk):
                             sl = slice(b0, min(n_all, b0 + blk))
                             ig, nb = HB.run_block(ws, hb["w0"], hb["fdat"], pts_a[sl], qs_a[sl], qv_a[sl], knn_a[sl], d_a[sl],
                                                   None if nz_a is None else nz_a[sl], None if d2_a is None else d2_a[sl], None if nz2_a is None else nz2_a[sl])
                             hip_state["scatter"].add(sl, HB.input_gradients(ig, nb))
+                    mark("fused backward blocks")
                     continue
                 block = spec.get("samples_per_block") or n_all
                 if spec.get("graph_blocks") and spec.get("samples_per_block"):
@@ -586,5 +599,9 @@ class PassGradient(torch.autograd.Function):
                 tabs = [sample_map(frame["feat_geo"][0], vert_xy), sample_map(frame["feat_geo"][1], vert_xy)]
                 accumulate(torch.autograd.grad(tabs, loc, [sc.acc["vtab0"], sc.acc["vtab1"]], allow_unused=True))
                 g_table = g_table + sc.acc["table29"]
+            mark("parameter gradients")
             accumulate(torch.autograd.grad(table_graph, loc, g_table, allow_unused=True))
+            mark("per-frame stacks backward")
+        if marks:
+            print("PassGradient.backward sections (ms):", [(b[0], round(1e3 * (b[1] - a[1]), 2)) for a, b in zip(marks, marks[1:])])
         return (None, *total)
