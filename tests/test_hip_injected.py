@@ -233,3 +233,26 @@ def test_model_training_pass_and_gt_gathers_vs_reference(golden, hot_weights):
         assert abs(float(r["err_dict"][k]) - v) <= 2e-3 * max(1.0, abs(v)), (k, float(r["err_dict"][k]), v)
     assert torch.is_tensor(r["loss"]) and abs(float(r["loss"]) - float(g["loss"])) <= 2e-3 * float(g["loss"])
     assert float((r["loss"] + 0.1 * torch.tensor(0.3, device="cuda")).item()) > float(r["loss"])  # training_step's arithmetic, src/model.py:405
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_every_outlier_of_the_uninjected_image_has_a_flipped_decision(R, sd_full, precision):
+    """The shipped path (HIP ray generator, no injection) against the oracle on 40 x 40 strided rays of the 512x334 benchmark view, 64 + 64
+    samples: whatever pixel exceeds 1e-4 must show a flipped discrete decision at one of its samples -- visibility flag, inside flag,
+    validity, a per-sample output jump, a fine sample in another cdf bin (bench.py: explain_outliers, which runs in every bench)."""
+    import bench
+    frame = synth.make_frame(seed=11, tar_h=512, tar_w=334, orbit_deg=15.0)
+    fd = synth.to_device(frame, "cuda")
+    sdd = {k: v.cuda() for k, v in sd_full.items() if k.startswith("tex_vis_fusion.")}
+    fdat = R.FrameData(sdd, fd["img_in"], fd["feat_geo"], fd["feat_tex"], fd["src_foreground_mask"], fd["cam_in"], fd["targets"], fd["sp_data"])
+    w = R.PackedWeights(sd_full, mode=precision)
+    S, side = 64, 40
+    _, ref, grids = bench.cpu_baseline(sd_full, frame, S, side)
+    px = grids[0].to(torch.int32).cuda().contiguous()
+    out = R.render_pass(w, fdat, frame["cam_tar"], frame["bounds"], 0, 0, 1, px.shape[0], 1, S, S, pixels=px)
+    want = ref["tex_fg_fine"][0].reshape(3, -1).t()
+    err = (out["color_fine"].cpu() - want).abs()
+    rep = bench.explain_outliers(R, w, fdat, frame, px, S, ref, err)
+    print(precision, rep)
+    assert rep["pixels_above_1e-4"] == rep["pixels_above_1e-4_with_a_flipped_decision"], rep
+    assert rep["pixels_above_1e-4"] <= 0.01 * side * side
