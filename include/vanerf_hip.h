@@ -123,6 +123,11 @@ int vanerf_ray_setup(int x0, int y0, int step_x, int step_y, int y_block, int nx
                      int64_t* index, float* rays_d, float* cam_pos, float* near, float* far, uint8_t* hit, float* z,
                      void* stream);
 
+/* ... with the rows as a list of blocks: row iy = row_blocks[iy / y_block] + (iy % y_block) * step_x (device table of ny / y_block entries): the
+ * shard of a multi-GPU view whose blocks of 8 rows were dealt by cost instead of round robin (vanerf_amd/parallel.py: deal_blocks)          */
+int vanerf_ray_setup_blocks(const int32_t* row_blocks, int x0, int step_x, int y_block, int nx, int ny, int width, const float* invK_T,
+                            const float* RT, float znear, float zfar, const float* bounds, int S, const float* t_lin, const float* jitter,
+                            int64_t* index, float* rays_d, float* cam_pos, float* near, float* far, uint8_t* hit, float* z, void* stream);
 /* Same with an explicit pixel list pixels_xy[n_rays][2] (int32, device): the training branch's clamped 64x64 window around a
  * random mask pixel (src/model.py:1172-1189) is not a regular grid.                                                         */
 int vanerf_ray_setup_pixels(const int32_t* pixels_xy, int n_rays, int width, const float* invK_T, const float* RT, float znear,
@@ -245,6 +250,7 @@ int vanerf_importance_sample(const float* contrib_inner, const float* z_mid, con
 typedef struct {
     int x0, y0, step_x, step_y, y_block, nx, ny; /* pixel grid as in vanerf_ray_setup (ignored when pixels_xy is given; then n_rays = nx * ny) */
     const int32_t* pixels_xy;  /* optional explicit pixel list [nx*ny][2] (device), as in vanerf_ray_setup_pixels */
+    const int32_t* row_blocks; /* optional first rows of the ny / y_block blocks of rows (device), as in vanerf_ray_setup_blocks (y0, step_y ignored) */
     int width;                 /* target image width (pixel index = x + y * width) */
     float invK_T[9], RT[12];   /* target camera: inverse(K[:3,:3]) transposed; [R|t] rows 0..2 */
     float znear, zfar;

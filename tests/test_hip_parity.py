@@ -1066,6 +1066,24 @@ def test_many_passes_in_flight_on_two_streams(R, sd_full, precision):
                 assert torch.equal(o[k], ref[k]), (si, i, k)
 
 
+def test_rows_given_as_a_list_of_blocks(R, sd_full):
+    """vanerf_ray_setup_blocks / VanerfPassDesc.row_blocks: a shard whose 8-row blocks come from a table (parallel.deal_blocks) renders the bits
+    those rows have in the whole image -- through the Python sequence and through the one-call C entry point."""
+    from vanerf_amd.parallel import block_rows, deal_blocks
+    frame = _frame(3, 64)
+    fdat = _frame_data(R, sd_full, frame)
+    w = R.PackedWeights(sd_full, mode="bf16x3")
+    full = R.render_pass(w, fdat, frame["cam_tar"], frame["bounds"], 0, 0, 1, 64, 64, 8, 8)
+    assign = deal_blocks(torch.tensor([1, 4, 9, 9, 6, 3, 1, 1], dtype=torch.float64), 2)
+    for rank in range(2):
+        first = block_rows(assign, rank).cuda()
+        rows = (first.long()[:, None] + torch.arange(8, device="cuda")[None]).reshape(-1)
+        for fn in (R.render_pass, R.render_pass_c):
+            o = fn(w, fdat, frame["cam_tar"], frame["bounds"], 0, 0, 1, 64, rows.numel(), 8, 8, y_block=8, row_blocks=first)
+            assert torch.equal(o["index"].view(-1, 64), full["index"].view(64, 64)[rows])
+            assert torch.equal(o["color_fine"].view(-1, 64, 3), full["color_fine"].view(64, 64, 3)[rows])
+
+
 def test_scatter_add_rows(R):
     """vanerf_scatter_add_rows (backward of the row gathers of a training step) against torch.index_add_: tables of 1 024 x 64, 16 384 x 8 and
     1 558 x 29 rows x channels, heavy index duplication, optional per-sample weights, out-of-range rows ignored, accumulation into a non-zero table."""

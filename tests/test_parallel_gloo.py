@@ -131,3 +131,46 @@ def test_four_rank_gather_of_row_blocks():
     res = _run_ranks(_worker4, world=4)
     assert [r[1] for r in res] == [True] * 4
     assert [r[2] for r in res] == [(8 * r, 32, 16, 8) for r in range(4)]
+
+
+def _worker_dealt(rank, world, port, q):
+    """8-row blocks dealt by cost (parallel.deal_blocks): every rank computes the same table, gathers equal tiles, rebuilds the image."""
+    from vanerf_amd.parallel import block_rows, deal_blocks, deinterleave_blocks
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    hh, ww = 8 * 13, 5  # 13 blocks over 4 ranks: three padding blocks below the image
+    img = torch.arange(hh * ww * 3, dtype=torch.float32).view(hh, ww, 3)
+    costs = torch.tensor([1, 1, 5, 9, 9, 5, 2, 1, 1, 3, 7, 2, 1], dtype=torch.float64)
+    assign = deal_blocks(costs, world)
+    first = block_rows(assign, rank)
+    rows = (first.long()[:, None] + torch.arange(8)[None]).reshape(-1)
+    padded = torch.cat([img, torch.zeros(8 * int(assign.max() + 1) - hh, ww, 3)], 0)  # rows below the image are rendered like any other
+    tile = padded[rows].reshape(-1, 3)
+    parts = [torch.empty_like(tile) for _ in range(world)]
+    dist.all_gather(parts, tile)
+    full = deinterleave_blocks(torch.cat(parts, 0), assign, hh, ww)
+    q.put((rank, torch.equal(full, img), assign.tolist()))
+    dist.destroy_process_group()
+
+
+def test_blocks_dealt_by_cost():
+    """deal_blocks: every block exactly once, the same number of blocks per rank (equal all-gather tiles), a balanced load, the same table on
+    every rank; the gathered tiles rebuild the image (four gloo ranks)."""
+    from vanerf_amd.parallel import deal_blocks
+    costs = torch.tensor([1, 1, 5, 9, 9, 5, 2, 1, 1, 3, 7, 2, 1], dtype=torch.float64)
+    for world in (1, 2, 4, 8):
+        a = deal_blocks(costs, world)
+        per = (13 + world - 1) // world
+        assert a.shape == (world, per)
+        assert sorted(a.reshape(-1).tolist()) == list(range(world * per))            # every block (and padding block) exactly once
+        loads = [sum(float(costs[b]) for b in r if b < 13) for r in a.tolist()]
+        assert max(loads) <= sum(loads) / world + float(costs.max())                 # greedy bound
+        assert all(r == sorted(r) for r in a.tolist())                               # image order inside a rank
+    # an uneven view: round robin puts the expensive middle rows on few ranks, the deal does not
+    uneven = torch.tensor([10.0, 1.0, 1.0, 1.0] * 2 + [1.0] * 8)  # (round robin gives rank 0 both expensive blocks)
+    a = deal_blocks(uneven, 4)
+    dealt = max(sum(float(uneven[b]) for b in r) for r in a.tolist())
+    rr = max(sum(float(uneven[b]) for b in range(16) if b % 4 == r) for r in range(4))
+    assert dealt < rr
+    res = _run_ranks(_worker_dealt, world=4)
+    assert [r[1] for r in res] == [True] * 4 and all(r[2] == res[0][2] for r in res)

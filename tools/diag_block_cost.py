@@ -23,3 +23,24 @@ for N in (2, 4, 8):
     sn = [sum(cost[b] for b in range(64) if (b % (2 * N) == r or b % (2 * N) == 2 * N - 1 - r)) for r in range(N)]
     mean = sum(cost) / N
     print(f"N={N}: round robin max/mean {max(rr) / mean:.3f}   snake max/mean {max(sn) / mean:.3f}")
+# proxies a rank can compute without rendering: rays of the block that hit the hands' bounding box; coarse samples that are valid (inside the
+# source view and its foreground mask) -- and how well a deal by each proxy balances the MEASURED costs (parallel.deal_blocks)
+from vanerf_amd.parallel import deal_blocks
+rays = R.ray_setup(frame["cam_tar"], frame["bounds"], 0, 0, 1, 334, 512, 64, device="cuda")
+hits = rays["hit"].view(64, -1).float().sum(1).cpu()
+pts = R.sample_points(rays["rays_d"], rays["cam_pos"], rays["z"])
+q_sdf, q_vis, knn = R.mesh_query_accel(fdat.accel, fdat.verts3, fdat.faces, fdat.vert_vis, pts)
+_, valid = R.query_samples(w, fdat, pts, q_sdf, q_vis, knn, want_valid=True, raw=True)
+vcount = valid.view(64, -1).float().sum(1).cpu()
+print("hit rays per block:", " ".join(f"{int(h)}" for h in hits))
+print("valid coarse samples per block (k):", " ".join(f"{v / 1e3:.0f}" for v in vcount))
+c = torch.tensor(cost, dtype=torch.float64)
+A = torch.stack([torch.ones(64, dtype=torch.float64), hits.double(), vcount.double()], 1)
+coef = torch.linalg.lstsq(A, c[:, None]).solution.view(-1)
+print("least squares: cost ~", [float(x) for x in coef], "* [1, hit rays, valid samples]; residual rms", float(((A @ coef) - c).pow(2).mean().sqrt()))
+for N in (2, 4, 8):
+    mean = sum(cost) / N
+    for name, proxy in (("measured", c), ("hits", 1.0 + hits.double() / 334.0), ("valid", 1.0 + vcount.double() / vcount.mean()), ("fit", A @ coef)):
+        a = deal_blocks(proxy, N)
+        loads = [sum(cost[b] for b in r if b < 64) for r in a.tolist()]
+        print(f"N={N}: dealt by {name:8s} max/mean {max(loads) / mean:.3f}")

@@ -56,7 +56,7 @@ class VanerfMeshAccel(Structure):
 class VanerfPassDesc(Structure):
     _fields_ = [
         ("x0", c_int), ("y0", c_int), ("step_x", c_int), ("step_y", c_int), ("y_block", c_int), ("nx", c_int), ("ny", c_int),
-        ("pixels_xy", _FP), ("width", c_int), ("invK_T", c_float * 9), ("RT", c_float * 12), ("znear", c_float), ("zfar", c_float),
+        ("pixels_xy", _FP), ("row_blocks", _FP), ("width", c_int), ("invK_T", c_float * 9), ("RT", c_float * 12), ("znear", c_float), ("zfar", c_float),
         ("bounds", c_float * 6), ("Sc", c_int), ("Sf", c_int), ("fine", c_int), ("reuse_coarse", c_int),
         ("t_lin_c", _FP), ("t_lin_f", _FP), ("jitter", _FP), ("u", _FP), ("noise_c", _FP), ("noise_f", _FP),
     ]
@@ -81,6 +81,8 @@ _SIGS = {
                                  POINTER(c_float), c_int, _FP, _FP, _FP, _FP, _FP, _FP, _FP, _FP, _FP, c_void_p]),
     "vanerf_ray_setup_pixels": (c_int, [_FP, c_int, c_int, POINTER(c_float), POINTER(c_float), c_float, c_float, POINTER(c_float), c_int, _FP, _FP,
                                         _FP, _FP, _FP, _FP, _FP, _FP, _FP, c_void_p]),
+    "vanerf_ray_setup_blocks": (c_int, [_FP, c_int, c_int, c_int, c_int, c_int, c_int, POINTER(c_float), POINTER(c_float), c_float, c_float,
+                                        POINTER(c_float), c_int, _FP, _FP, _FP, _FP, _FP, _FP, _FP, _FP, _FP, c_void_p]),
     "vanerf_sample_points": (c_int, [_FP, _FP, _FP, c_int, c_int, _FP, c_void_p]),
     "vanerf_vertex_visibility": (c_int, [_FP, _FP, c_int, _FP, c_int, c_int, _FP, _FP, c_void_p]),
     "vanerf_mesh_query": (c_int, [_FP, c_int, _FP, c_int, _FP, _FP, c_int64, _FP, _FP, _FP, c_void_p]),

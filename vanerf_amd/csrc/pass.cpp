@@ -101,6 +101,9 @@ extern "C" int vanerf_render_pass(const VanerfWeights* w, const VanerfFrame* fra
         if (d.pixels_xy)
             ok(vanerf_ray_setup_pixels(d.pixels_xy, R, d.width, d.invK_T, d.RT, d.znear, d.zfar, d.bounds, Sc, d.t_lin_c, d.jitter, o.index, L.rays_d,
                                        L.cam_pos, L.near, L.far, o.hit, o.z, stream), "ray setup");
+        else if (d.row_blocks)
+            ok(vanerf_ray_setup_blocks(d.row_blocks, d.x0, d.step_x, d.y_block, d.nx, d.ny, d.width, d.invK_T, d.RT, d.znear, d.zfar, d.bounds, Sc, d.t_lin_c,
+                                       d.jitter, o.index, L.rays_d, L.cam_pos, L.near, L.far, o.hit, o.z, stream), "ray setup");
         else
             ok(vanerf_ray_setup(d.x0, d.y0, d.step_x, d.step_y, d.y_block, d.nx, d.ny, d.width, d.invK_T, d.RT, d.znear, d.zfar, d.bounds, Sc, d.t_lin_c,
                                 d.jitter, o.index, L.rays_d, L.cam_pos, L.near, L.far, o.hit, o.z, stream), "ray setup");

@@ -14,6 +14,7 @@ namespace {
 struct RayParams {
     int x0, y0, step_x, step_y, y_block, nx, ny, width;
     const int32_t* pixels; // optional explicit (x, y) list of nx*ny pixels (training patches), else the regular grid
+    const int32_t* row_blocks; // optional first row of every block of y_block rows (multi-GPU shards dealt by cost), else y0 + block * step_y
     float invK_T[9];
     float RT[12];
     float znear, zfar;
@@ -94,7 +95,8 @@ __global__ __launch_bounds__(256) void ray_setup_kernel(const RayParams P)
     if (r < R) {
     const int ix = r % P.nx, iy = r / P.nx;
     const int gxi = P.pixels ? P.pixels[2 * r] : P.x0 + ix * P.step_x;
-    const int gyi = P.pixels ? P.pixels[2 * r + 1] : P.y0 + (iy / P.y_block) * P.step_y + (iy % P.y_block) * P.step_x;
+    const int gyi = P.pixels ? P.pixels[2 * r + 1]
+                             : (P.row_blocks ? P.row_blocks[iy / P.y_block] : P.y0 + (iy / P.y_block) * P.step_y) + (iy % P.y_block) * P.step_x;
     P.index[r] = (int64_t)gxi + (int64_t)gyi * P.width;
     const float gx = (float)gxi, gy = (float)gyi;
     const float* K = P.invK_T; // row-major 3x3: c_j = gx*K[0][j] + gy*K[1][j] + K[2][j]
@@ -306,7 +308,7 @@ __global__ __launch_bounds__(IM_BLOCK) void importance_merge_kernel(const float*
 
 } // namespace
 
-static void ray_setup_impl(const int32_t* pixels, int x0, int y0, int step_x, int step_y, int y_block, int nx, int ny, int width, const float* invK_T,
+static void ray_setup_impl(const int32_t* pixels, const int32_t* row_blocks, int x0, int y0, int step_x, int step_y, int y_block, int nx, int ny, int width, const float* invK_T,
                            const float* RT, float znear, float zfar, const float* bounds, int S, const float* t_lin, const float* jitter,
                            int64_t* index, float* rays_d, float* cam_pos, float* near, float* far, uint8_t* hit, float* z, void* stream);
 
@@ -316,7 +318,21 @@ extern "C" int vanerf_ray_setup(int x0, int y0, int step_x, int step_y, int y_bl
                                 void* stream)
 {
     return guarded([&] {
-        ray_setup_impl(nullptr, x0, y0, step_x, step_y, y_block, nx, ny, width, invK_T, RT, znear, zfar, bounds, S, t_lin, jitter, index, rays_d,
+        ray_setup_impl(nullptr, nullptr, x0, y0, step_x, step_y, y_block, nx, ny, width, invK_T, RT, znear, zfar, bounds, S, t_lin, jitter, index, rays_d,
+                       cam_pos, near, far, hit, z, stream);
+    });
+}
+
+// the same grid with the rows given as a list of blocks: row iy is row_blocks[iy / y_block] + (iy % y_block) * step_x (device table of ny / y_block
+// entries) -- a multi-GPU shard whose 8-row blocks were dealt by cost (vanerf_amd/parallel.py: deal_blocks) instead of round robin
+extern "C" int vanerf_ray_setup_blocks(const int32_t* row_blocks, int x0, int step_x, int y_block, int nx, int ny, int width, const float* invK_T,
+                                       const float* RT, float znear, float zfar, const float* bounds, int S, const float* t_lin, const float* jitter,
+                                       int64_t* index, float* rays_d, float* cam_pos, float* near, float* far, uint8_t* hit, float* z, void* stream)
+{
+    return guarded([&] {
+        if (!row_blocks) throw_error("vanerf_ray_setup_blocks: null block list");
+        if (y_block <= 0 || ny % y_block != 0) throw_error("vanerf_ray_setup_blocks: ny = %d is not a whole number of blocks of %d rows", ny, y_block);
+        ray_setup_impl(nullptr, row_blocks, x0, 0, step_x, 1, y_block, nx, ny, width, invK_T, RT, znear, zfar, bounds, S, t_lin, jitter, index, rays_d,
                        cam_pos, near, far, hit, z, stream);
     });
 }
@@ -327,12 +343,12 @@ extern "C" int vanerf_ray_setup_pixels(const int32_t* pixels_xy, int n_rays, int
 {
     return guarded([&] {
         if (!pixels_xy) throw_error("vanerf_ray_setup_pixels: null pixel list");
-        ray_setup_impl(pixels_xy, 0, 0, 1, 1, 1, n_rays, 1, width, invK_T, RT, znear, zfar, bounds, S, t_lin, jitter, index, rays_d, cam_pos,
+        ray_setup_impl(pixels_xy, nullptr, 0, 0, 1, 1, 1, n_rays, 1, width, invK_T, RT, znear, zfar, bounds, S, t_lin, jitter, index, rays_d, cam_pos,
                        near, far, hit, z, stream);
     });
 }
 
-static void ray_setup_impl(const int32_t* pixels, int x0, int y0, int step_x, int step_y, int y_block, int nx, int ny, int width, const float* invK_T,
+static void ray_setup_impl(const int32_t* pixels, const int32_t* row_blocks, int x0, int y0, int step_x, int step_y, int y_block, int nx, int ny, int width, const float* invK_T,
                            const float* RT, float znear, float zfar, const float* bounds, int S, const float* t_lin, const float* jitter,
                            int64_t* index, float* rays_d, float* cam_pos, float* near, float* far, uint8_t* hit, float* z, void* stream)
 {
@@ -342,7 +358,7 @@ static void ray_setup_impl(const int32_t* pixels, int x0, int y0, int step_x, in
         if (nx <= 0 || ny <= 0 || step_x <= 0 || step_y <= 0 || y_block <= 0 || S < 2 || width <= 0)
             throw_error("vanerf_ray_setup: bad grid (nx=%d ny=%d step=%d,%d S=%d)", nx, ny, step_x, step_y, S);
         RayParams P;
-        P.x0 = x0; P.y0 = y0; P.step_x = step_x; P.step_y = step_y; P.y_block = y_block; P.nx = nx; P.ny = ny; P.width = width; P.pixels = pixels;
+        P.x0 = x0; P.y0 = y0; P.step_x = step_x; P.step_y = step_y; P.y_block = y_block; P.nx = nx; P.ny = ny; P.width = width; P.pixels = pixels; P.row_blocks = row_blocks;
         std::copy_n(invK_T, 9, P.invK_T);
         std::copy_n(RT, 12, P.RT);
         std::copy_n(bounds, 6, P.bounds);

@@ -40,6 +40,46 @@ def deinterleave(gathered, height, width, world, channels=3):
     return g.permute(1, 0, 2, 3, 4).reshape(hp, width, channels)[:height]
 
 
+def deal_blocks(costs, world):
+    """Blocks of 8 rows dealt to the ranks by COST instead of round robin: `costs` (n_blocks,) -- e.g. every block's ray / valid-sample count in
+    the previous frame of an orbit, identical on all ranks -- -> assign (world, per) long tensor of block indices, per = ceil(n_blocks / world):
+    every rank gets the SAME number of blocks (the all-gather needs equal tiles; indices >= n_blocks are padding blocks below the image) and
+    the largest load is as small as a greedy deal makes it: blocks in order of falling cost, each to the least loaded rank that still has
+    room (ties by rank: deterministic, so every rank computes the same table).  Within a rank the blocks are kept in image order."""
+    costs = torch.as_tensor(costs, dtype=torch.float64).reshape(-1).cpu()
+    nb = costs.numel()
+    per = (nb + world - 1) // world
+    order = sorted(range(nb), key=lambda b: (-float(costs[b]), b))
+    load, rooms, mine = [0.0] * world, [per] * world, [[] for _ in range(world)]
+    for b in order:
+        r = min((r for r in range(world) if rooms[r] > 0), key=lambda r: (load[r], r))
+        mine[r].append(b)
+        load[r] += float(costs[b])
+        rooms[r] -= 1
+    pad = nb
+    for r in range(world):
+        while len(mine[r]) < per:
+            mine[r].append(pad)
+            pad += 1
+        mine[r].sort()
+    return torch.tensor(mine, dtype=torch.long)
+
+
+def block_rows(assign, rank):
+    """First image row of each of `rank`'s blocks (int32, for renderer.render_pass(row_blocks=...)) -- padding blocks start below the image."""
+    return (assign[rank] * ROW_BLOCK).to(torch.int32)
+
+
+def deinterleave_blocks(gathered, assign, height, width, channels=3):
+    """all_gather output [rank][block of the rank][row in block][x][c] -> image (height, width, c) for a deal_blocks table."""
+    world, per = assign.shape
+    g = gathered.view(world * per, ROW_BLOCK, width, channels)
+    n_slots = world * per
+    full = torch.empty(n_slots, ROW_BLOCK, width, channels, dtype=gathered.dtype, device=gathered.device)
+    full[assign.reshape(-1).to(gathered.device)] = g
+    return full.view(n_slots * ROW_BLOCK, width, channels)[:height]
+
+
 def gather_image(tile, height, width, world, group=None):
     """tile: this rank's (rows*width, C) tensor -> full (height, width, C) image on every rank."""
     if world == 1:

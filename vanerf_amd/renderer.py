@@ -491,10 +491,11 @@ def ray_bbox(bounds, orig, dirs):
     return near, far, hit
 
 
-def ray_setup(cam_tar, bounds, x0, y0, step, nx, ny, S, jitter=None, device=None, y_step=None, pixels=None, y_block=1):
+def ray_setup(cam_tar, bounds, x0, y0, step, nx, ny, S, jitter=None, device=None, y_step=None, pixels=None, y_block=1, row_blocks=None):
     """Pixel grid + rays + bbox clip + coarse depths (src/model.py:1191-1238, 1496-1570).
     pixels: optional explicit (R,2) int32 device tensor of (x, y) (training patches); then nx*ny must equal R.
-    y_step, y_block: rows are y0 + (iy // y_block) * y_step + (iy % y_block) * step (multi-GPU shards: blocks of y_block rows)."""
+    y_step, y_block: rows are y0 + (iy // y_block) * y_step + (iy % y_block) * step (multi-GPU shards: blocks of y_block rows).
+    row_blocks: optional (ny // y_block,) int32 device tensor, the first row of every block (shards dealt by cost: parallel.deal_blocks)."""
     dev = device or bounds.device
     K, RT = host_copy(cam_tar["K"]), host_copy(cam_tar["RT"])
     inv_K_T = torch.inverse(K[:, :3, :3]).transpose(1, 2)[0].contiguous()  # th.inverse(...).transpose(1, 2), model.py:1208
@@ -512,6 +513,9 @@ def ray_setup(cam_tar, bounds, x0, y0, step, nx, ny, S, jitter=None, device=None
     if pixels is not None:
         assert pixels.shape == (R, 2)
         check(lib.vanerf_ray_setup_pixels(_ptr(pixels, torch.int32), R, int(cam_tar["width"]), *cam_args))
+    elif row_blocks is not None:
+        assert row_blocks.dtype == torch.int32 and row_blocks.is_cuda and row_blocks.numel() * int(y_block) == ny
+        check(lib.vanerf_ray_setup_blocks(_ptr(row_blocks, torch.int32), int(x0), int(step), int(y_block), int(nx), int(ny), int(cam_tar["width"]), *cam_args))
     else:
         check(lib.vanerf_ray_setup(int(x0), int(y0), int(step), int(y_step or step), int(y_block), int(nx), int(ny), int(cam_tar["width"]), *cam_args))
     return dict(index=index, rays_d=rays_d, cam_pos=cam_pos, near=near, far=far, hit=hit, z=z)
@@ -533,7 +537,7 @@ PARTITION_MIN_SAMPLES = 1 << 18
 
 def render_pass(weights, frame, cam_tar, bounds, x0, y0, step, nx, ny, sample_per_ray_c=64, sample_per_ray_f=64, fine=True,
                 jitter=None, u=None, noise_std=0.0, generator=None, debug=False, kernel_events=None, y_step=None, reuse_coarse=True,
-                pixels=None, y_block=1, inject=None, noise_draws=None):
+                pixels=None, y_block=1, inject=None, noise_draws=None, row_blocks=None):
     """Returns flat per-ray tensors: color/depth/alpha (coarse), color_fine/depth_fine/alpha_fine/sdf (fine), index, z, z_fine.
 
     noise_draws: optional (coarse, fine) standard-normal draws (flat, one per evaluated sample) used instead of fresh ones when
@@ -553,7 +557,7 @@ def render_pass(weights, frame, cam_tar, bounds, x0, y0, step, nx, ny, sample_pe
     the fine batch holds at their sorted positions.  Same bits as re-evaluating (tests/test_hip_parity.py), 1/3 less work."""
     Sc, Sf = int(sample_per_ray_c), int(sample_per_ray_f)
     rays = ray_setup(cam_tar, bounds, x0, y0, step, nx, ny, Sc, jitter=jitter, device=frame.verts3.device, y_step=y_step, pixels=pixels,
-                     y_block=y_block)
+                     y_block=y_block, row_blocks=row_blocks)
     R = nx * ny
     if inject is not None:
         for k in ("rays_d", "cam_pos", "z"):
@@ -647,7 +651,7 @@ def render_pass(weights, frame, cam_tar, bounds, x0, y0, step, nx, ny, sample_pe
 
 
 def render_pass_c(weights, frame, cam_tar, bounds, x0, y0, step, nx, ny, sample_per_ray_c=64, sample_per_ray_f=64, fine=True, jitter=None, u=None,
-                  noise_std=0.0, generator=None, y_step=None, reuse_coarse=True, pixels=None, y_block=1, noise_draws=None):
+                  noise_std=0.0, generator=None, y_step=None, reuse_coarse=True, pixels=None, y_block=1, noise_draws=None, row_blocks=None):
     """The same pass through the single C entry point vanerf_render_pass (include/vanerf_hip.h): one ctypes call enqueues every kernel of
     render_pass() above, in the same order with the same arguments -- the outputs are bit-identical (tests/test_hip_parity.py) -- with all
     temporaries in one scratch block.  This is what a non-Python host binds; the model's eval / no-grad passes go through it too."""
@@ -657,6 +661,7 @@ def render_pass_c(weights, frame, cam_tar, bounds, x0, y0, step, nx, ny, sample_
     d = VanerfPassDesc()
     d.x0, d.y0, d.step_x, d.step_y, d.y_block, d.nx, d.ny = int(x0), int(y0), int(step), int(y_step or step), int(y_block), int(nx), int(ny)
     d.pixels_xy = _ptr(pixels, torch.int32)
+    d.row_blocks = _ptr(row_blocks, torch.int32)
     d.width = int(cam_tar["width"])
     d.invK_T = _farr(torch.inverse(K[:, :3, :3]).transpose(1, 2)[0].reshape(-1).tolist(), 9)
     d.RT = _farr(RT[0, :3, :4].reshape(-1).tolist(), 12)
