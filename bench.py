@@ -24,6 +24,9 @@ if REPO not in sys.path:
 
 FLOP_PER_SAMPLE = 2 * 143772          # 143 772 MAC per sample evaluation (V = 1)
 FLOP_PER_INVALID_SAMPLE = 2 * (3072 + 22848)  # ibr_compress + TexVisFusion only: all that an invalid sample needs
+# bf16x3 kernel: a block of all-invalid groups reads ibr_compress's (constant) output from LDS instead of running the layer, so those samples are
+# priced WITHOUT it (the groups that sit in a block with valid samples still run it: priced low, never high)
+FLOP_PER_INVALID_SAMPLE_BF16X3 = 2 * 22848
 PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_BF16_MFMA_TFLOPS = 2516.8        # MI355X_MICROARCH.md: ~2.5 PF dense bf16 (16 x the fp32 matrix rate)
 DEFAULT_PRECISION = "bf16x3"    # the north star asks for bf16 MFMA tiles at 1e-4 of the fp32 reference: met by the split-bf16 mode
@@ -202,7 +205,7 @@ def main():
     k_samples = [n for _, _, n in events]
     kern_s = sum(k_ms) / 1e3
     short_samples = 32 * (weights.short_groups() - short0)
-    flops = (sum(k_samples) - short_samples) * FLOP_PER_SAMPLE + short_samples * FLOP_PER_INVALID_SAMPLE
+    flops = (sum(k_samples) - short_samples) * FLOP_PER_SAMPLE + short_samples * (FLOP_PER_INVALID_SAMPLE_BF16X3 if bf else FLOP_PER_INVALID_SAMPLE)
     achieved = flops / kern_s / 1e12
     # HBM bytes per launch.  NOT measured in this run (counters need a rocprofv3 --pmc pass of their own): a static figure from the committed
     # PMC passes of this kernel, scaled by samples per launch; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B).

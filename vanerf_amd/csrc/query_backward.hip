@@ -38,7 +38,6 @@ struct BwdParams {
     float* ig;              // [IG_ROWS][npad]
 };
 
-__device__ __forceinline__ int row0(int reg) { return (reg & 3) + 8 * (reg >> 2); }
 constexpr int crow0(int reg) { return (reg & 3) + 8 * (reg >> 2); }
 
 // pass P of layer L's backward: acc[blocks of the pass] = W^T dY over the layer's kBT k-pairs; dy(t'') = this lane's D register t''

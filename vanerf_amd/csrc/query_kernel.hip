@@ -148,14 +148,16 @@ constexpr bool W2 = VANERF_WAVES_PER_SIMD_B == 2;
 //   [1024, 1024 + 32 KB)     fragment ring (two-wave build)               [LDS_RES, LDS_RES + RES_DW * 4)  resident fragments
 constexpr bool RING = VANERF_RING != 0;
 constexpr unsigned RING_PHASE_PIECES = 16u, RING_BYTES = RING ? 2u * RING_PHASE_PIECES * 1024u : 0u; // two halves of one 16 KB phase each
-constexpr unsigned LDS_KPT = 0u, LDS_CTRL = 2u * PE_KPT_PER_HALF * 16u, LDS_RING = 1024u, LDS_RES = RING ? LDS_RING + RING_BYTES : 768u;
+constexpr unsigned LDS_KPT = 0u, LDS_CTRL = 2u * PE_KPT_PER_HALF * 16u, LDS_LAT0 = 768u, LDS_RING = 1024u, LDS_RES = RING ? LDS_RING + RING_BYTES : 1024u;
+// [768, 896): ibr_compress of an all-zero pooled latent (its bias through the same MFMA chain), [lane half][16 registers]: what every sample of an
+// all-invalid group gets from that layer -- computed once per block, read by the short path instead of 27 MFMAs per group
 constexpr unsigned DYN_LDS_BYTES = LDS_RES + RES_DW * 4u;
 // The streamed part of the fragment stream (layers 0 .. LDS_FIRST-1) as 1 KB pieces (one (k-step, output block, hi | lo) fragment each = one
 // LDS-DMA wave instruction), in the order the layers consume them; a PHASE is 16 consecutive pieces.
 constexpr unsigned RING_PIECES = RES_BASE_DW / 256u, RING_PHASES = ((RING_PIECES + RING_PHASE_PIECES - 1u) / RING_PHASE_PIECES + 1u) / 2u * 2u;
 static_assert(!RING || VANERF_WPB_B == 8, "the ring's DMA schedule deals 2 pieces of a phase to each of 8 waves");
 static_assert(!RING || RING_PHASES * RING_PHASE_PIECES * 256u <= layer_offset_b(NUM_LAYERS), "the last phase's DMA must stay inside the stream");
-static_assert(LDS_CTRL + 8u + 2u * 4u * VANERF_WPB_B <= LDS_RES, "control words overlap the resident fragments");
+static_assert(LDS_CTRL + 8u + 2u * 4u * VANERF_WPB_B <= LDS_LAT0 && LDS_LAT0 + 128u <= LDS_RING, "control words / constant latent overlap their neighbours");
 static_assert(DYN_LDS_BYTES <= 160u * 1024u, "key points + control words + resident fragments must fit the CU's 160 KB");
 extern __shared__ __attribute__((aligned(16))) u32x4 s_dyn[];
 typedef __attribute__((address_space(3))) u32x4 lds_u32x4_t;
@@ -661,6 +663,19 @@ __global__ __launch_bounds__(64 * WPB<MODE>, MODE == 1 ? VANERF_WAVES_PER_SIMD_B
         }
     }
     __syncthreads();
+    if constexpr (MODE == 1) { // the short path's constant latent (wave 0; the layer's fragments are resident by now)
+        if (wv_u == 0u) {
+            const LAddr la0 = make_laddr(lane, wv_u);
+            auto r0 = ring_start_m<MODE, 1, 65, L_IBR>(W, la0);
+            f32x16 lat0[1];
+            zero<1>(lat0);
+            const float one0 = (lane >> 5) ? 0.0f : 1.0f;
+            run_layer_m<MODE, 1, 65, L_IBR>(lat0, r0, W, la0, [&](auto tc) -> float { return decltype(tc)::value < 64 ? 0.0f : one0; });
+            if ((lane & 31) == 0)
+                static_for<16>([&](auto rc) { constexpr int r = decltype(rc)::value; reinterpret_cast<lds_u32_t*>((size_t)LDS_LAT0)[(lane >> 5) * 16 + r] = __float_as_uint(lat0[0][r]); });
+        }
+        __syncthreads();
+    }
     unsigned base_cur = s_base(0);
     if (threadIdx.x == 0) pending = atomicAdd(P.queue, (unsigned)WAVES_PER_BLOCK);
     SampleIn in_next = fetch(base_cur + wv, j);
@@ -937,13 +952,21 @@ __global__ __launch_bounds__(64 * WPB<MODE>, MODE == 1 ? VANERF_WAVES_PER_SIMD_B
         }
         if (!wave_valid && lane == 0 && g < ngroups) ++short_groups; // counted by the wave's own samples (what bench.py prices), not by the block's path
         if constexpr (MODE == 1 && W2) tex_gathers();
-        auto r_ibr = ring_start_m<MODE, 1, 65, L_IBR>(W, la);
         STAMP(7); // pool + head
         // ---- ibr_compress_gfeat 128 -> 24 (src/model.py:921) ------------------------------------------------
-        auto r_ta = ring_start_m<MODE, 3, 49, L_TEX_AT_A>(W, la);
         f32x16 lat[1];
-        zero<1>(lat);
-        run_layer_m<MODE, 1, 65, L_IBR>(lat, r_ibr, W, la, [&](auto tc) -> float { return chain(pool, tc, std::integral_constant<int, 64>{}); });
+        typename RingSel<MODE, 3>::type r_ta;
+        if (MODE == 1 && !any_valid) {
+            // all-invalid group: the pooled latent is exactly zero, the layer returns its bias -- the block's constant (same chain, same bits)
+            r_ta = ring_start_m<MODE, 3, 49, L_TEX_AT_A>(W, la);
+            if constexpr (MODE == 1)
+                static_for<16>([&](auto rc) { constexpr int r = decltype(rc)::value; lat[0][r] = __uint_as_float(reinterpret_cast<const lds_u32_t*>((size_t)LDS_LAT0)[h * 16 + r]); });
+        } else {
+            auto r_ibr = ring_start_m<MODE, 1, 65, L_IBR>(W, la);
+            r_ta = ring_start_m<MODE, 3, 49, L_TEX_AT_A>(W, la);
+            zero<1>(lat);
+            run_layer_m<MODE, 1, 65, L_IBR>(lat, r_ibr, W, la, [&](auto tc) -> float { return chain(pool, tc, std::integral_constant<int, 64>{}); });
+        }
         STAMP(8); // ibr
         // ---- TexVisFusion per-sample part (src/networks.py:281-293) -----------------------------------------
         f32x16 rgb[1];
