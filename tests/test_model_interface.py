@@ -186,3 +186,18 @@ def test_bicubic_upsampling_as_matrix_products_matches_the_library_call():
         assert (ga - gb).abs().max() <= 2e-5
         with torch.no_grad():
             assert torch.equal(_bicubic_up2(x.detach()), b.detach())  # inference: the library call itself
+
+
+def test_ibr_head_forward_for_two_views_matches_the_reference(golden, hot_weights):
+    """IBRRenderingHead.forward (src/model.py:1600-1636) of the drop-in module at V = 2 against the reference's own output
+    (tests/golden/ibr_head_v2.npz), and at V = 1 its identity: the colour is the first three feature channels."""
+    from vanerf_amd.model import IBRRenderingHead
+    g = golden("ibr_head_v2")
+    head = IBRRenderingHead()
+    missing = head.load_state_dict({k[len("mlp_tex."):]: v for k, v in hot_weights.items() if k.startswith("mlp_tex.")}, strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    with torch.no_grad():
+        out = head(g["rgb_feats"], g["ray_diffs"], g["proj_mask"])
+        assert out.shape == g["out"].shape and (out - g["out"]).abs().max() <= 1e-6
+        one = head(g["rgb_feats"][:, :, :1], g["ray_diffs"][:, :, :1], torch.ones_like(g["proj_mask"][:, :, :1]))
+        assert torch.equal(one, g["rgb_feats"][:, :, 0, :3])

@@ -92,8 +92,8 @@ class MLPUNetFusion(nn.Module):
 
 
 class IBRRenderingHead(nn.Module):
-    """Parameters of src/model.py:1572-1591.  At n_views == 1 its output is exactly rgb_feat[..., :3] (softmax over a single
-    view, src/model.py:1613, 1635), so the HIP path never evaluates it; the parameters exist for checkpoint compatibility."""
+    """src/model.py:1572-1636.  At n_views == 1 its output is exactly rgb_feat[..., :3] (softmax over a single view, src/model.py:1613,
+    1635), so the HIP path never evaluates it; the parameters exist for checkpoint compatibility, forward() for completeness (V >= 1)."""
 
     def __init__(self, in_channels=32 + 5, **kwargs):
         super().__init__()
@@ -104,6 +104,25 @@ class IBRRenderingHead(nn.Module):
         self.vis_layer1 = nn.Sequential(nn.Linear(32, 32), nn.ELU(inplace=True), nn.Linear(32, 33), nn.ELU(inplace=True))
         self.vis_layer2 = nn.Sequential(nn.Linear(32, 32), nn.ELU(inplace=True), nn.Linear(32, 1), nn.Sigmoid())
         self.out_layer = nn.Sequential(nn.Linear(37, 16), nn.ELU(inplace=True), nn.Linear(16, 8), nn.ELU(inplace=True), nn.Linear(8, 1))
+
+    def forward(self, rgb_feats, ray_diffs, proj_mask):
+        """src/model.py:1600-1636 for any number of views V: (R,S,V,40), (R,S,V,4), (R,S,V,1) -> (R,S,3).  Plain PyTorch (the per-sample kernel
+        covers V = 1, where this reduces to rgb_feats[..., :3]); here so that the module is whole for callers that evaluate the head themselves."""
+        views = rgb_feats.shape[2]
+        colours = rgb_feats[..., :3]
+        enc = self.ray_encoder(ray_diffs)
+        feats = torch.cat([rgb_feats[..., :enc.shape[-1]] + enc, rgb_feats[..., enc.shape[-1]:]], -1)
+        closeness = torch.exp(self.ani_al.abs() * (ray_diffs[..., 3:4] - 1.0))
+        w = (closeness - closeness.amin(2, keepdim=True)) * proj_mask
+        w = w / (w.sum(2, keepdim=True) + 1e-8)
+        mean = (feats * w).sum(2, keepdim=True)                      # fused_mean_variance, src/utils.py:153-157
+        var = (w * (feats - mean).square()).sum(2, keepdim=True)
+        x = self.base_layer(torch.cat([mean.expand(-1, -1, views, -1), var.expand(-1, -1, views, -1), feats], -1))
+        extra = self.vis_layer1(x * w)
+        x = x + extra[..., :-1]
+        vis = self.vis_layer2(x * torch.sigmoid(extra[..., -1:]) * proj_mask) * proj_mask
+        score = self.out_layer(torch.cat([x, vis, ray_diffs], -1)).masked_fill(proj_mask == 0, -1e4)
+        return (colours * torch.softmax(score, 2)).sum(2)
 
 
 class SpatialEncoder(nn.Module):
