@@ -72,3 +72,31 @@ def test_product_path_has_no_cpu_fallback(ffi):
     from vanerf_amd import renderer
     with pytest.raises(ValueError):
         renderer.knn1(torch.zeros(4, 4), torch.zeros(2, 3))  # CPU tensors are refused, never silently computed
+
+
+def test_backward_spill_layout_is_consistent(ffi, hot_weights):
+    """The host-only description of the fused backward's spills (vanerf_spill_rows / vanerf_layer_rows / vanerf_layer_slots): row bases tile the
+    spills without overlap, and every layer's slot table names each input channel of the reference's parameter exactly as often as the kernel
+    gathers it (once, except the duplicated pool/visibility operands), with a bias slot exactly where the reference layer has a bias."""
+    from vanerf_amd import hip_backward as hb
+    L = hb.layout()
+    assert (L["x_rows"], L["y_rows"], L["aux_rows"], L["ig_rows"]) == (2074, 965, 110, 286)
+    assert len(L["layers"]) == ffi.NUM_LAYERS == len(hb.LAYER_PARAMS)
+    sd = dict(hot_weights)
+    x_at = y_at = flat = 0
+    for lay, spec in zip(L["layers"], hb.LAYER_PARAMS):
+        assert lay["x_row"] == x_at and lay["y_row"] == y_at and lay["flat"] == flat
+        x_at += lay["n_slots"]; y_at += lay["n_out"]; flat += lay["n_out"] * lay["n_slots"]
+        ref = sd[spec[1]] if spec[0] == "conv" else sd[spec[1] + (".weight_v" if spec[0] == "wn" else ".weight")]
+        kin = ref.shape[1]
+        sl = lay["slots"]
+        assert lay["n_out"] <= ref.shape[0]  # fconv.2: 3 of 40 output channels (one view)
+        assert ((sl >= -2) & (sl < kin)).all()
+        assert int((sl == -2).sum()) == (0 if spec[0] == "conv" else 1), spec
+        seen = torch.bincount(sl[sl >= 0], minlength=kin)
+        assert (seen >= 1).all(), (spec, (seen == 0).nonzero().view(-1).tolist())  # no channel of the parameter without a slot
+    assert (x_at, y_at, flat) == (L["x_rows"], L["y_rows"], L["flat"])
+    # argument checks of the host-only entry points
+    assert ffi.lib.vanerf_layer_slots(20, None, 0) < 0 and ffi.lib.vanerf_layer_slots(-1, None, 0) < 0
+    buf = (ctypes.c_int32 * 4)()
+    assert ffi.lib.vanerf_layer_slots(8, ctypes.cast(buf, ctypes.c_void_p), 4) < 0  # capacity below the layer's slot count
