@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define VANERF_ABI_VERSION 9
+#define VANERF_ABI_VERSION 10
 
 #define VANERF_OK 0
 #define VANERF_EINVAL (-22)
@@ -103,11 +103,23 @@ const char* vanerf_last_error(void);
  *              outputs within 3.3e-5 of mode 0 on the 10.9 M-sample benchmark launch, about twice as fast */
 int vanerf_weights_pack(const VanerfWeightTable* w, int mode, VanerfWeights** out);
 int vanerf_weights_free(VanerfWeights* w);
+/* Re-packs a handle IN PLACE from parameters that live on the DEVICE (the training step: the optimiser has just changed them).  `dev` is a
+ * weight table of device pointers to the parameters' own storage (fp32, contiguous); sigmoid_beta_dev points at the parameter on the device
+ * (NULL: dev->sigmoid_beta, a host value, is taken).  A few launches on `stream`, no copy to the host, no allocation after the first call, nothing
+ * blocks; the streams are bit-identical to a fresh vanerf_weights_pack of the same values.  The caller orders the update after the launches
+ * that still read the old weights (same stream, or an event).                                                                                  */
+int vanerf_weights_update(VanerfWeights* w, const VanerfWeightTable* dev, const float* sigmoid_beta_dev, void* stream);
 /* Diagnostics: number of 32-sample groups (since the pack) for which vanerf_query_samples took its all-invalid short path
  * (only the colour branch evaluated).  Blocking device read; for benchmarks and tests.                                        */
 int vanerf_weights_short_groups(const VanerfWeights* w, uint64_t* count);
 /* Host-only view of the packed fragment stream (no GPU touched): out[cap] or NULL to query the size; offsets[20]. */
 int vanerf_weights_pack_host(const VanerfWeightTable* w, float* out, int64_t cap, int64_t* n_out, unsigned* offsets);
+/* Host-only view of any stream a handle can carry: which = 0 the fp32 forward stream, 1 the bf16x3 forward stream (32-bit words of two bf16
+ * each, copied raw), 2 the transposed fp32 stream of the fused backward pass.  out[cap] or NULL to query the size.                            */
+int vanerf_weights_stream_host(const VanerfWeightTable* w, int which, float* out, int64_t cap, int64_t* n_out);
+/* The streams a handle holds on the device, copied back to host memory (blocking; for tests of vanerf_weights_update): which = 0 the forward
+ * stream of the handle's mode, 2 the backward stream (fp32 handles only).                                                                       */
+int vanerf_weights_download(const VanerfWeights* w, int which, float* out, int64_t cap, int64_t* n_out);
 
 /* a1-a4  Pixel grid, ray generation, bbox clipping, coarse depths (src/model.py:1191-1238, 1496-1570).
  *   grid: x = x0 + ix*step_x, y = y0 + (iy / y_block)*step_y + (iy % y_block)*step_x for iy < ny (outer), ix < nx (inner); R = nx*ny rays

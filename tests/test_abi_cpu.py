@@ -25,7 +25,7 @@ def test_exports_match_header(ffi):
     assert declared == set(ffi.EXPORTS)
     for name in declared:
         assert hasattr(ffi.lib, name), name
-    assert ffi.lib.vanerf_abi_version() == ffi.ABI_VERSION == 9
+    assert ffi.lib.vanerf_abi_version() == ffi.ABI_VERSION == 10
 
 
 def test_error_convention(ffi):

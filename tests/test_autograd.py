@@ -333,3 +333,27 @@ def test_graphed_encoders_give_the_same_step():
         assert set(grad_a) == set(grad_b) and any(k.startswith("geo_encoder.") for k in grad_a)
         for k in grad_a:
             assert (grad_a[k] - grad_b[k]).norm() <= 2e-2 * grad_a[k].norm() + 1e-4, (it, k)
+
+
+def test_steps_repack_the_weights_on_the_device():
+    """After the optimiser's step both weight handles (the forward's and the fp32 one of the fused backward) are re-packed in place on the device
+    (vanerf_weights_update); the streams they then hold must be the bits a fresh host pack of the module's parameters gives, step after step,
+    and the handles themselves stay the same objects (no allocation, no blocking copy in the step)."""
+    from vanerf_amd import renderer as R
+    net = _net(0.01)
+    frame = synth.to_device(synth.make_frame(seed=3, tar_h=64, tar_w=64), "cuda")
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+    handles = None
+    for it in range(3):
+        out = _step(net, frame)
+        held = (net._packed[1], net._packed_alt[1])
+        sd = {k: v.detach().cpu() for k, v in net._hot_state().items()}
+        assert torch.equal(R.stream_device(held[0], 0), R.stream_host(sd, 1)), it
+        assert torch.equal(R.stream_device(held[1], 0), R.stream_host(sd, 0)), it
+        assert torch.equal(R.stream_device(held[1], 2), R.stream_host(sd, 2)), it
+        assert handles is None or (held[0] is handles[0] and held[1] is handles[1])
+        handles = held
+        opt.zero_grad(set_to_none=True)
+        ((out["tex_fg_fine"] - out["tar_img"]).abs().mean() + out["alpha_fine"].mean()).backward()
+        opt.step()
+    assert abs(held[0].beta - max(float(net.sigmoid_beta.detach()), 2e-3)) < 1e-9

@@ -1084,6 +1084,35 @@ def test_rows_given_as_a_list_of_blocks(R, sd_full):
             assert torch.equal(o["color_fine"].view(-1, 64, 3), full["color_fine"].view(64, 64, 3)[rows])
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_weights_update_on_the_device_equals_a_fresh_pack(R, sd_full, precision):
+    """vanerf_weights_update: a handle packed from one set of weights and re-packed IN PLACE from another set that lives on the device holds the
+    bits a fresh host pack of that set holds -- forward stream, backward stream (fp32 handles), sigmoid_beta -- and renders the same image."""
+    which = {"fp32": 0, "bf16x3": 1}[precision]
+    other = synth.make_full_weights(7)
+    other["sigmoid_beta"] = torch.tensor([0.07])
+    w = R.PackedWeights(sd_full, mode=precision)
+    assert torch.equal(R.stream_device(w, 0), R.stream_host(sd_full, which))
+    on_dev = {k: v.cuda() for k, v in other.items()}
+    w.update(on_dev)
+    assert torch.equal(R.stream_device(w, 0), R.stream_host(other, which))
+    if precision == "fp32":
+        assert torch.equal(R.stream_device(w, 2), R.stream_host(other, 2))
+    assert abs(w.beta - 0.07) < 1e-9
+    frame = _frame(3, 32)
+    fdat = _frame_data(R, sd_full, frame)
+    fresh = R.PackedWeights(other, mode=precision)
+    a = R.render_pass_c(w, fdat, frame["cam_tar"], frame["bounds"], 0, 0, 1, 32, 32, 8, 8)
+    b = R.render_pass_c(fresh, fdat, frame["cam_tar"], frame["bounds"], 0, 0, 1, 32, 32, 8, 8)
+    for k in ("color", "alpha", "color_fine", "alpha_fine", "depth_fine"):
+        assert torch.equal(a[k], b[k]), k  # the composites read sigmoid_beta from the handle's device copy
+    on_dev["sigmoid_beta"].fill_(1e-4)  # below the clamp of sdf_activation (src/model.py:880)
+    w.update(on_dev)
+    assert w.beta == 2e-3
+    with pytest.raises(ValueError):
+        w.update(other)  # host tensors: the device packer refuses, it never copies
+
+
 def test_scatter_add_rows(R):
     """vanerf_scatter_add_rows (backward of the row gathers of a training step) against torch.index_add_: tables of 1 024 x 64, 16 384 x 8 and
     1 558 x 29 rows x channels, heavy index duplication, optional per-sample weights, out-of-range rows ignored, accumulation into a non-zero table."""

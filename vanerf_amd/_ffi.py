@@ -12,7 +12,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int64, c_uint
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VANERF_HIP_LIB") or os.path.join(_HERE, "lib", "libvanerf_hip.so")  # the override is for A/B runs of kernel builds (tools/)
-ABI_VERSION = 9
+ABI_VERSION = 10
 NUM_LAYERS = 20
 
 if not os.path.exists(LIB_PATH):
@@ -75,8 +75,11 @@ _SIGS = {
     "vanerf_mesh_accel_build": (c_int, [_FP, c_int, _FP, c_int, c_int, c_int, c_void_p, c_int64, POINTER(VanerfMeshAccel), c_void_p]),
     "vanerf_weights_pack": (c_int, [POINTER(VanerfWeightTable), c_int, POINTER(c_void_p)]),
     "vanerf_weights_free": (c_int, [c_void_p]),
+    "vanerf_weights_update": (c_int, [c_void_p, POINTER(VanerfWeightTable), _FP, c_void_p]),
     "vanerf_weights_short_groups": (c_int, [c_void_p, POINTER(c_uint64)]),
     "vanerf_weights_pack_host": (c_int, [POINTER(VanerfWeightTable), _FP, c_int64, POINTER(c_int64), POINTER(c_uint)]),
+    "vanerf_weights_stream_host": (c_int, [POINTER(VanerfWeightTable), c_int, _FP, c_int64, POINTER(c_int64)]),
+    "vanerf_weights_download": (c_int, [c_void_p, c_int, _FP, c_int64, POINTER(c_int64)]),
     "vanerf_ray_setup": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, POINTER(c_float), POINTER(c_float), c_float, c_float,
                                  POINTER(c_float), c_int, _FP, _FP, _FP, _FP, _FP, _FP, _FP, _FP, _FP, c_void_p]),
     "vanerf_ray_setup_pixels": (c_int, [_FP, c_int, c_int, POINTER(c_float), POINTER(c_float), c_float, c_float, POINTER(c_float), c_int, _FP, _FP,

@@ -2,6 +2,8 @@
 #include <algorithm>
 #include <cstddef>
 
+#include <cstring>
+
 #include "common.h"
 
 namespace vanerf {
@@ -40,10 +42,13 @@ extern "C" int vanerf_weights_pack(const VanerfWeightTable* w, int mode, VanerfW
         if (e == hipSuccess && !host_bwd.empty()) e = hipMemcpy(h->dev_bwd, host_bwd.data(), host_bwd.size() * sizeof(float), hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMalloc(&h->stats, sizeof(unsigned long long));
         if (e == hipSuccess) e = hipMemset(h->stats, 0, sizeof(unsigned long long));
+        if (e == hipSuccess) e = hipMalloc(&h->dev_beta, sizeof(float));
+        if (e == hipSuccess) e = hipMemcpy(h->dev_beta, &h->beta, sizeof(float), hipMemcpyHostToDevice);
         if (e != hipSuccess) {
             if (h->dev) (void)hipFree(h->dev);
             if (h->dev_bwd) (void)hipFree(h->dev_bwd);
             if (h->stats) (void)hipFree(h->stats);
+            if (h->dev_beta) (void)hipFree(h->dev_beta);
             delete h;
             hip_check(e, "vanerf_weights_pack: device upload");
         }
@@ -58,6 +63,8 @@ extern "C" int vanerf_weights_free(VanerfWeights* w)
         if (w->dev) HIP_CHECK(hipFree(w->dev));
         if (w->dev_bwd) HIP_CHECK(hipFree(w->dev_bwd));
         if (w->stats) HIP_CHECK(hipFree(w->stats));
+        if (w->dev_beta) HIP_CHECK(hipFree(w->dev_beta));
+        if (w->dev_eff) HIP_CHECK(hipFree(w->dev_eff));
         delete w;
     });
 }
@@ -75,6 +82,44 @@ extern "C" int vanerf_weights_pack_host(const VanerfWeightTable* w, float* out, 
         if (out) {
             if (cap < (int64_t)host.size()) throw_error("vanerf_weights_pack_host: buffer too small");
             std::copy(host.begin(), host.end(), out);
+        }
+    });
+}
+
+// Host-only view of any of the three streams a handle can carry: which = 0 the fp32 forward stream, 1 the bf16x3 forward stream (32-bit words
+// of two bf16 each, returned as raw floats), 2 the transposed fp32 stream of the fused backward pass.
+extern "C" int vanerf_weights_stream_host(const VanerfWeightTable* w, int which, float* out, int64_t cap, int64_t* n_out)
+{
+    return guarded([&] {
+        if (!w || !n_out) throw_error("vanerf_weights_stream_host: null argument");
+        if (which < 0 || which > 2) throw_error("vanerf_weights_stream_host: which = %d (0 fp32, 1 bf16x3, 2 backward)", which);
+        std::vector<float> host, bwd;
+        LayerOffsets offs{};
+        pack_weights_host(*w, host, offs, which == 1 ? 1 : 0, which == 2 ? &bwd : nullptr);
+        const std::vector<float>& src = which == 2 ? bwd : host;
+        *n_out = (int64_t)src.size();
+        if (out) {
+            if (cap < (int64_t)src.size()) throw_error("vanerf_weights_stream_host: buffer too small");
+            std::memcpy(out, src.data(), src.size() * sizeof(float)); // raw copy: the bf16x3 words are not numbers
+        }
+    });
+}
+
+// The streams a handle holds on the device, copied back (blocking; tests of vanerf_weights_update): which = 0 the forward stream of the handle's
+// mode, 2 the backward stream (fp32 handles).
+extern "C" int vanerf_weights_download(const VanerfWeights* w, int which, float* out, int64_t cap, int64_t* n_out)
+{
+    return guarded([&] {
+        if (!w || !n_out) throw_error("vanerf_weights_download: null argument");
+        if (which != 0 && which != 2) throw_error("vanerf_weights_download: which = %d (0 forward, 2 backward)", which);
+        const float* src = which ? w->dev_bwd : w->dev;
+        const size_t n = which ? w->n_floats_bwd : w->n_floats;
+        if (!src) throw_error("vanerf_weights_download: the handle carries no such stream");
+        *n_out = (int64_t)n;
+        if (out) {
+            if (cap < (int64_t)n) throw_error("vanerf_weights_download: buffer too small");
+            HIP_CHECK(hipDeviceSynchronize());
+            HIP_CHECK(hipMemcpy(out, src, n * sizeof(float), hipMemcpyDeviceToHost));
         }
     });
 }

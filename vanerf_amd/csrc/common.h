@@ -64,7 +64,27 @@ int guarded(F&& fn) noexcept
 }
 
 void pack_weights_host(const VanerfWeightTable& w, std::vector<float>& out, LayerOffsets& offs, int mode = 0, std::vector<float>* bwd = nullptr);
+// The packer's two stages (weights_pack.cpp): where a layer's parameters are and where its effective weights go in the flat array `eff` ...
+struct LayerSrc {
+    const float* w; // [nout][kin] (weight-normed layers: weight_v)
+    const float* g; // weight_g or null
+    const float* b; // bias or null
+    int nout, kin;
+    unsigned eff;   // offset of the layer in eff: [nout][kin], then the bias
+};
+void layer_sources(const VanerfWeightTable& w, LayerSrc out[NUM_LAYERS]);
+// ... and the placement of eff in the streams: out[i] = id ? eff[id - 1] : 0.  fwd / bwd: the fp32 forward stream and the transposed stream of
+// the fused backward; fwd_b: the bf16x3 stream, two ints per 32-bit word (low half's id | part << 30, high half's id; part 0 = high bf16 part).
+struct PackTables {
+    std::vector<int> fwd, bwd, fwd_b;
+    LayerOffsets offs{};
+    unsigned n_eff = 0;
+};
+const PackTables& pack_tables();
 int layer_slots(int layer, int* k_of_slot, int cap);
+
+void composite_with_handle(const VanerfWeights* w, const float* rgba, const float* z, const float* msdf, const float* rgba_b, const float* msdf_b,
+                           const int32_t* src, int Sa, int Sb, int R, float* color, float* depth, float* alpha, float* sdf, float* contrib, void* stream);
 
 } // namespace vanerf
 
@@ -75,7 +95,9 @@ struct VanerfWeights {
     size_t n_floats = 0;
     vanerf::LayerOffsets offs{};
     int mode = 0;
-    float beta = 0.1f;
+    float beta = 0.1f;      // sigmoid_beta as packed from the host (clamped); stale once vanerf_weights_update took it from the device ...
+    float* dev_beta = nullptr; // ... so the passes' composites read this device copy (one float, clamped)
+    float* dev_eff = nullptr;  // vanerf_weights_update's stage 1: the effective weights (allocated at the first update)
     int device = 0;
     unsigned long long* stats = nullptr; // [0]: running count of 32-sample groups that took query_kernel's all-invalid short path
 };

@@ -124,7 +124,7 @@ extern "C" int vanerf_render_pass(const VanerfWeights* w, const VanerfFrame* fra
             ok(vanerf_query_samples(w, frame, L.pts, q_sdf, L.q_vis, L.knn, noise, order, 0, n, rgba, nullptr, qw + 1, stream), "per-sample networks");
         };
         march(o.z, Sc, d.noise_c, L.q_sdf_c, L.rgba_c);
-        ok(vanerf_composite(L.rgba_c, o.z, L.q_sdf_c, R, Sc, w->beta, o.color, o.depth, o.alpha, L.s1, L.contrib, stream), "coarse composite");
+        composite_with_handle(w, L.rgba_c, o.z, L.q_sdf_c, nullptr, nullptr, nullptr, Sc, 0, R, o.color, o.depth, o.alpha, L.s1, L.contrib, stream);
         if (!fine) return;
         float* z_fine = o.z_fine ? o.z_fine : L.z_fine;
         float* cf = o.color_fine ? o.color_fine : L.color_f3;
@@ -134,11 +134,10 @@ extern "C" int vanerf_render_pass(const VanerfWeights* w, const VanerfFrame* fra
         ok(vanerf_importance_merge(L.contrib, o.z, d.u, d.u ? nullptr : d.t_lin_f, R, Sc, Sf, L.z_new, z_fine, L.src, nullptr, stream), "importance sampling");
         if (reuse) {
             march(L.z_new, Sf, nullptr, L.q_sdf_f, L.rgba_f);
-            ok(vanerf_composite_merged(L.rgba_c, L.q_sdf_c, Sc, L.rgba_f, L.q_sdf_f, Sf, L.src, z_fine, R, w->beta, cf, df, af, sf, nullptr, stream),
-               "fine composite");
+            composite_with_handle(w, L.rgba_c, z_fine, L.q_sdf_c, L.rgba_f, L.q_sdf_f, L.src, Sc, Sf, R, cf, df, af, sf, nullptr, stream);
         } else {
             march(z_fine, Sc + Sf, d.noise_f, L.q_sdf_f, L.rgba_f);
-            ok(vanerf_composite(L.rgba_f, z_fine, L.q_sdf_f, R, Sc + Sf, w->beta, cf, df, af, sf, nullptr, stream), "fine composite");
+            composite_with_handle(w, L.rgba_f, z_fine, L.q_sdf_f, nullptr, nullptr, nullptr, Sc + Sf, 0, R, cf, df, af, sf, nullptr, stream);
         }
     });
 }

@@ -159,11 +159,12 @@ __global__ void sample_points_kernel(const float* __restrict__ rays_d, const flo
 // composite gives the same bits as evaluating them again (the reference re-evaluates them, src/model.py:1305-1345).
 __global__ void composite_kernel(const float* __restrict__ rgba, const float* __restrict__ z, const float* __restrict__ msdf,
                                  const float* __restrict__ rgba_b, const float* __restrict__ msdf_b, const int32_t* __restrict__ src,
-                                 int Sa, int Sb, int R, int S, float beta, float* __restrict__ color, float* __restrict__ depth,
+                                 int Sa, int Sb, int R, int S, float beta, const float* __restrict__ beta_dev, float* __restrict__ color, float* __restrict__ depth,
                                  float* __restrict__ alpha, float* __restrict__ sdf, float* __restrict__ contrib)
 {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= R) return;
+    if (beta_dev) beta = *beta_dev; // a handle re-packed on the device (vanerf_weights_update) carries sigmoid_beta there, already clamped
     const float* qa = rgba + (size_t)r * Sa * 5;
     const float* ma = msdf + (size_t)r * Sa;
     const float* qb = rgba_b ? rgba_b + (size_t)r * Sb * 5 : nullptr;
@@ -389,13 +390,14 @@ extern "C" int vanerf_sample_points(const float* rays_d, const float* cam_pos, c
 template <int SPL>
 __global__ __launch_bounds__(256) void composite_wave_kernel(const float* __restrict__ rgba, const float* __restrict__ z, const float* __restrict__ msdf,
                                                              const float* __restrict__ rgba_b, const float* __restrict__ msdf_b,
-                                                             const int32_t* __restrict__ src, int Sa, int Sb, int R, int S, float beta,
+                                                             const int32_t* __restrict__ src, int Sa, int Sb, int R, int S, float beta, const float* __restrict__ beta_dev,
                                                              float* __restrict__ color, float* __restrict__ depth, float* __restrict__ alpha,
                                                              float* __restrict__ sdf, float* __restrict__ contrib)
 {
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= R) return; // whole wave
+    if (beta_dev) beta = *beta_dev; // a handle re-packed on the device (vanerf_weights_update) carries sigmoid_beta there, already clamped
     const float* qa = rgba + (size_t)r * Sa * 5;
     const float* ma = msdf + (size_t)r * Sa;
     const float* qb = rgba_b ? rgba_b + (size_t)r * Sb * 5 : nullptr;
@@ -462,25 +464,33 @@ __global__ __launch_bounds__(256) void composite_wave_kernel(const float* __rest
 }
 
 static void launch_composite(const float* rgba, const float* z, const float* msdf, const float* rgba_b, const float* msdf_b,
-                             const int32_t* src, int Sa, int Sb, int R, int S, float beta, float* color, float* depth, float* alpha,
-                             float* sdf, float* contrib, void* stream)
+                             const int32_t* src, int Sa, int Sb, int R, int S, float beta, const float* beta_dev, float* color, float* depth,
+                             float* alpha, float* sdf, float* contrib, void* stream)
 {
     if (R <= 0 || S <= 0) throw_error("vanerf_composite: R=%d S=%d", R, S);
-    if (!(beta > 0.0f)) throw_error("vanerf_composite: beta must be positive");
+    if (!beta_dev && !(beta > 0.0f)) throw_error("vanerf_composite: beta must be positive");
     if (beta < 2e-3f) beta = 2e-3f; // sdf_activation clamp (src/model.py:880)
     const dim3 wg((R + 3) / 4), wb(256);
 #define VANERF_COMPOSITE_WAVE(SPL)                                                                                                  \
     hipLaunchKernelGGL(composite_wave_kernel<SPL>, wg, wb, 0, (hipStream_t)stream, rgba, z, msdf, rgba_b, msdf_b, src, Sa, Sb, R, S, beta, \
-                       color, depth, alpha, sdf, contrib)
+                       beta_dev, color, depth, alpha, sdf, contrib)
     if (S <= 64) VANERF_COMPOSITE_WAVE(1);
     else if (S <= 128) VANERF_COMPOSITE_WAVE(2);
     else if (S <= 192) VANERF_COMPOSITE_WAVE(3);
     else if (S <= 256) VANERF_COMPOSITE_WAVE(4);
     else // more than 256 samples per ray: one thread per ray
         hipLaunchKernelGGL(composite_kernel, dim3((R + 63) / 64), dim3(64), 0, (hipStream_t)stream, rgba, z, msdf, rgba_b, msdf_b, src, Sa, Sb,
-                           R, S, beta, color, depth, alpha, sdf, contrib);
+                           R, S, beta, beta_dev, color, depth, alpha, sdf, contrib);
 #undef VANERF_COMPOSITE_WAVE
     HIP_CHECK(hipGetLastError());
+}
+
+// pass.cpp's composites: sigmoid_beta from the weight handle's device copy (see vanerf_weights_update); rgba_b == null: one table of S = Sa samples
+void vanerf::composite_with_handle(const VanerfWeights* w, const float* rgba, const float* z, const float* msdf, const float* rgba_b, const float* msdf_b,
+                                   const int32_t* src, int Sa, int Sb, int R, float* color, float* depth, float* alpha, float* sdf, float* contrib,
+                                   void* stream)
+{
+    launch_composite(rgba, z, msdf, rgba_b, msdf_b, src, Sa, Sb, R, Sa + Sb, w->beta, w->dev_beta, color, depth, alpha, sdf, contrib, stream);
 }
 
 extern "C" int vanerf_composite(const float* rgba, const float* z, const float* mesh_sdf, int R, int S, float beta,
@@ -488,7 +498,7 @@ extern "C" int vanerf_composite(const float* rgba, const float* z, const float* 
 {
     return guarded([&] {
         if (!rgba || !z || !mesh_sdf || !color || !depth || !alpha || !sdf) throw_error("vanerf_composite: null argument");
-        launch_composite(rgba, z, mesh_sdf, nullptr, nullptr, nullptr, S, 0, R, S, beta, color, depth, alpha, sdf, contrib, stream);
+        launch_composite(rgba, z, mesh_sdf, nullptr, nullptr, nullptr, S, 0, R, S, beta, nullptr, color, depth, alpha, sdf, contrib, stream);
     });
 }
 
@@ -500,7 +510,7 @@ extern "C" int vanerf_composite_merged(const float* rgba_c, const float* mesh_sd
         if (!rgba_c || !mesh_sdf_c || !rgba_n || !mesh_sdf_n || !src || !z_fine || !color || !depth || !alpha || !sdf)
             throw_error("vanerf_composite_merged: null argument");
         if (Sc <= 0 || Sn <= 0) throw_error("vanerf_composite_merged: Sc=%d Sn=%d", Sc, Sn);
-        launch_composite(rgba_c, z_fine, mesh_sdf_c, rgba_n, mesh_sdf_n, src, Sc, Sn, R, Sc + Sn, beta, color, depth, alpha, sdf, contrib, stream);
+        launch_composite(rgba_c, z_fine, mesh_sdf_c, rgba_n, mesh_sdf_n, src, Sc, Sn, R, Sc + Sn, beta, nullptr, color, depth, alpha, sdf, contrib, stream);
     });
 }
 

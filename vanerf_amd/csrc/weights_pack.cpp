@@ -1,5 +1,10 @@
 // weights_pack.cpp -- folds weight-norm and permutes the reference's [out][in] weight matrices into
-// the MFMA fragment streams described in layer_spec.h.  Host side; one hipMemcpy per pack.
+// the MFMA fragment streams described in layer_spec.h.
+// Two stages: (1) the EFFECTIVE weights, one flat fp32 array `eff` (every layer's [out][in] matrix with weight-norm folded, then its bias);
+// (2) PLACEMENT, a pure gather out[i] = eff[id[i] - 1] (id 0 = the constant 0; the bf16x3 stream also splits the value into its two bf16
+// parts).  The placement tables depend on layer_spec.h only, are built once per process and serve both the host packer
+// (vanerf_weights_pack: one hipMemcpy per pack) and the device packer (weights_update.hip: vanerf_weights_update re-packs a handle in place
+// from parameters that live on the device, two launches per stream, no synchronisation -- the training step's path).
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -35,29 +40,42 @@ void chain(Pairs& p, int nb, int nregs_last, int base, int kin_limit)
 
 void bias_pair(Pairs& p) { p.emplace_back(BIAS, ZERO); }
 
+// A layer's [out][in] matrix (+ bias) as the packer sees it.  The placement tables are built from matrices whose "values" are ids: 1 + the
+// element's index in `eff` (exact in fp32: eff has ~150 k entries).
 struct Mat {
-    std::vector<float> w; // effective [nout][kin]
+    std::vector<float> w; // [nout][kin]
     std::vector<float> b; // [nout] or empty
     int nout, kin;
 };
 
-Mat plain(const float* w, const float* b, int nout, int kin)
-{
-    Mat m{std::vector<float>(w, w + (size_t)nout * kin), {}, nout, kin};
-    if (b) m.b.assign(b, b + nout);
-    return m;
-}
+struct WordB { int id0, id1, part; }; // one 32-bit word of the bf16x3 stream: bf16 part `part` (0 high, 1 low) of eff[id0 - 1] | eff[id1 - 1] << 16
 
-// torch.nn.utils.weight_norm, dim=0: W[o][:] = g[o] * v[o][:] / ||v[o][:]||_2 (src/utils.py:674-675)
-Mat weight_normed(const float* v, const float* g, const float* b, int nout, int kin)
+// shapes of the twenty layers: rows used, input channels, bias, weight-norm (the reference's modules: include/vanerf_hip.h, VanerfWeightTable)
+struct Shape { int nout, kin, bias, wn; };
+constexpr Shape kShape[NUM_LAYERS] = {
+    {10, 196, 0, 0}, {3, 10, 0, 0}, {64, 196, 0, 0}, {64, 64, 0, 0}, {10, 28, 0, 0}, {3, 10, 0, 0}, {8, 28, 0, 0}, {8, 8, 0, 0},
+    {128, 358, 1, 1}, {128, 128, 1, 1}, {120, 136, 1, 1}, {64, 120, 1, 0}, {64, 128, 1, 1}, {64, 64, 1, 1}, {2, 64, 1, 0}, {24, 128, 1, 0},
+    {96, 96, 0, 0}, {6, 96, 0, 0}, {96, 96, 0, 0},
+    {3, 96, 0, 0}, // IBRRenderingHead at V = 1 returns rgb_feat[..., :3] exactly (src/model.py:1613, 1635): rows 0..2 of 40
+};
+constexpr unsigned eff_offset(int l)
 {
-    Mat m{std::vector<float>((size_t)nout * kin), std::vector<float>(b, b + nout), nout, kin};
-    for (int o = 0; o < nout; ++o) {
-        // torch: v * (g / norm(v)); norm accumulates in fp32 (vectorised); double here, error << 1 ulp of W
-        double s = 0.0;
-        for (int k = 0; k < kin; ++k) s += (double)v[(size_t)o * kin + k] * (double)v[(size_t)o * kin + k];
-        float scale = g[o] / (float)std::sqrt(s);
-        for (int k = 0; k < kin; ++k) m.w[(size_t)o * kin + k] = v[(size_t)o * kin + k] * scale;
+    unsigned o = 0;
+    for (int i = 0; i < l; ++i) o += (unsigned)(kShape[i].nout * kShape[i].kin + (kShape[i].bias ? kShape[i].nout : 0));
+    return o;
+}
+static_assert(eff_offset(NUM_LAYERS) < (1u << 24), "ids must be exact in fp32");
+
+Mat id_matrix(int l)
+{
+    const Shape sh = kShape[l];
+    if (sh.nout != kNOUT[l]) throw_error("internal: layer %d has %d outputs, spec says %d", l, sh.nout, kNOUT[l]);
+    Mat m{std::vector<float>((size_t)sh.nout * sh.kin), {}, sh.nout, sh.kin};
+    const unsigned base = eff_offset(l) + 1u;
+    for (size_t i = 0; i < m.w.size(); ++i) m.w[i] = (float)(base + i);
+    if (sh.bias) {
+        m.b.resize(sh.nout);
+        for (int o = 0; o < sh.nout; ++o) m.b[o] = (float)(base + m.w.size() + o);
     }
     return m;
 }
@@ -83,46 +101,30 @@ void emit(std::vector<float>& out, int layer, const Mat& m, const Pairs& pairs)
         }
 }
 
-inline unsigned short bf16_rne(float f)
-{
-    unsigned u;
-    std::memcpy(&u, &f, 4);
-    return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
-}
-inline float bf16_to_f32(unsigned short b)
-{
-    unsigned u = (unsigned)b << 16;
-    float f;
-    std::memcpy(&f, &u, 4);
-    return f;
-}
-
-// bf16x3 stream of one layer (layer_spec.h): element j of the 8-element fragment of lane (r, h) at step s is k-pair 8s + j
-void emit_b(std::vector<float>& out, int layer, const Mat& m, const Pairs& pairs)
+// bf16x3 stream of one layer (layer_spec.h): element j of the 8-element fragment of lane (r, h) at step s is k-pair 8s + j.
+// Placement only: per 32-bit word of the stream two ids (the elements in its low and high half) and which bf16 part of them it holds.
+void emit_b_ids(std::vector<WordB>& out, int layer, const Mat& m, const Pairs& pairs)
 {
     const int nb = kNB[layer], T = kT[layer], S = steps_b(layer);
     if ((int)pairs.size() != T) throw_error("internal: layer %d has %d k-pairs, spec says %d", layer, (int)pairs.size(), T);
     size_t base = out.size();
-    out.resize(base + layer_dwords_b(layer), 0.0f);
-    unsigned* dst = reinterpret_cast<unsigned*>(out.data() + base);
+    out.resize(base + layer_dwords_b(layer), WordB{0, 0, 0});
+    WordB* dst = out.data() + base;
     for (int s = 0; s < S; ++s)
         for (int ob = 0; ob < nb; ++ob)
             for (int lane = 0; lane < 64; ++lane) {
                 const int o = ob * 32 + (lane & 31);
-                unsigned short hi[8] = {}, lo[8] = {};
+                int id[8] = {};
                 for (int j = 0; j < 8; ++j) {
                     const int t = 8 * s + j;
                     if (t >= T || o >= m.nout) continue;
                     const int k = (lane >> 5) ? pairs[t].second : pairs[t].first;
                     if (k == ZERO) continue;
-                    const float v = (k == BIAS) ? (m.b.empty() ? 0.0f : m.b[o]) : m.w[(size_t)o * m.kin + k];
-                    hi[j] = bf16_rne(v);
-                    lo[j] = bf16_rne(v - bf16_to_f32(hi[j]));
+                    id[j] = (int)((k == BIAS) ? (m.b.empty() ? 0.0f : m.b[o]) : m.w[(size_t)o * m.kin + k]);
                 }
                 for (int part = 0; part < 2; ++part) {
-                    const unsigned short* e = part ? lo : hi;
-                    unsigned* q = dst + ((((size_t)s * nb + ob) * 2 + part) * 64 + lane) * 4;
-                    for (int i = 0; i < 4; ++i) q[i] = (unsigned)e[2 * i] | ((unsigned)e[2 * i + 1] << 16);
+                    WordB* q = dst + ((((size_t)s * nb + ob) * 2 + part) * 64 + lane) * 4;
+                    for (int i = 0; i < 4; ++i) q[i] = WordB{id[2 * i], id[2 * i + 1], part};
                 }
             }
 }
@@ -183,33 +185,60 @@ Pairs layer_pairs(int l)
     throw_error("internal: no layer %d", l);
 }
 
-// effective [out][in] matrix (+ bias) of every layer (weight-norm folded)
-Mat layer_matrix(const VanerfWeightTable& w, int l)
+// where every layer's parameters sit in a weight table (host or device pointers alike)
+void sources(const VanerfWeightTable& w, vanerf::LayerSrc out[NUM_LAYERS])
 {
-    switch (l) {
-    case L_GEO_AT0_A: return plain(w.geo_at0_w1, nullptr, 10, 196);
-    case L_GEO_AT0_B: return plain(w.geo_at0_w2, nullptr, 3, 10);
-    case L_GEO_ATED0_A: return plain(w.geo_ated0_w1, nullptr, 64, 196);
-    case L_GEO_ATED0_B: return plain(w.geo_ated0_w2, nullptr, 64, 64);
-    case L_GEO_AT1_A: return plain(w.geo_at1_w1, nullptr, 10, 28);
-    case L_GEO_AT1_B: return plain(w.geo_at1_w2, nullptr, 3, 10);
-    case L_GEO_ATED1_A: return plain(w.geo_ated1_w1, nullptr, 8, 28);
-    case L_GEO_ATED1_B: return plain(w.geo_ated1_w2, nullptr, 8, 8);
-    case L_MLP0: return weight_normed(w.l1_v[0], w.l1_g[0], w.l1_b[0], 128, 358);
-    case L_MLP1: return weight_normed(w.l1_v[1], w.l1_g[1], w.l1_b[1], 128, 128);
-    case L_MLP2: return weight_normed(w.l1_v[2], w.l1_g[2], w.l1_b[2], 120, 136);
-    case L_MLP3: return plain(w.l1_w3, w.l1_b3, 64, 120);
-    case L_HEAD0: return weight_normed(w.l2_v[0], w.l2_g[0], w.l2_b[0], 64, 128);
-    case L_HEAD1: return weight_normed(w.l2_v[1], w.l2_g[1], w.l2_b[1], 64, 64);
-    case L_HEAD2: return plain(w.l2_w2, w.l2_b2, 2, 64);
-    case L_IBR: return plain(w.ibr_w, w.ibr_b, 24, 128);
-    case L_TEX_AT_A: return plain(w.tex_at_w1, nullptr, 96, 96);
-    case L_TEX_AT_B: return plain(w.tex_at_w2, nullptr, 6, 96);
-    case L_TEX_A: return plain(w.tex_w1, nullptr, 96, 96);
-    // IBRRenderingHead at V = 1 returns rgb_feat[..., :3] exactly (src/model.py:1613, 1635): rows 0..2 of 40
-    case L_TEX_B: return plain(w.tex_w2, nullptr, 3, 96);
+    auto set = [&](int l, const float* ww, const float* g, const float* b) {
+        const Shape sh = kShape[l];
+        if (!ww || (sh.wn && !g) || (sh.bias && !b)) throw_error("weight table: a pointer of layer %d is null", l);
+        out[l] = vanerf::LayerSrc{ww, sh.wn ? g : nullptr, sh.bias ? b : nullptr, sh.nout, sh.kin, eff_offset(l)};
+    };
+    set(L_GEO_AT0_A, w.geo_at0_w1, nullptr, nullptr);
+    set(L_GEO_AT0_B, w.geo_at0_w2, nullptr, nullptr);
+    set(L_GEO_ATED0_A, w.geo_ated0_w1, nullptr, nullptr);
+    set(L_GEO_ATED0_B, w.geo_ated0_w2, nullptr, nullptr);
+    set(L_GEO_AT1_A, w.geo_at1_w1, nullptr, nullptr);
+    set(L_GEO_AT1_B, w.geo_at1_w2, nullptr, nullptr);
+    set(L_GEO_ATED1_A, w.geo_ated1_w1, nullptr, nullptr);
+    set(L_GEO_ATED1_B, w.geo_ated1_w2, nullptr, nullptr);
+    set(L_MLP0, w.l1_v[0], w.l1_g[0], w.l1_b[0]);
+    set(L_MLP1, w.l1_v[1], w.l1_g[1], w.l1_b[1]);
+    set(L_MLP2, w.l1_v[2], w.l1_g[2], w.l1_b[2]);
+    set(L_MLP3, w.l1_w3, nullptr, w.l1_b3);
+    set(L_HEAD0, w.l2_v[0], w.l2_g[0], w.l2_b[0]);
+    set(L_HEAD1, w.l2_v[1], w.l2_g[1], w.l2_b[1]);
+    set(L_HEAD2, w.l2_w2, nullptr, w.l2_b2);
+    set(L_IBR, w.ibr_w, nullptr, w.ibr_b);
+    set(L_TEX_AT_A, w.tex_at_w1, nullptr, nullptr);
+    set(L_TEX_AT_B, w.tex_at_w2, nullptr, nullptr);
+    set(L_TEX_A, w.tex_w1, nullptr, nullptr);
+    set(L_TEX_B, w.tex_w2, nullptr, nullptr);
+}
+
+// stage 1 on the host: eff from host pointers.  torch.nn.utils.weight_norm, dim=0: W[o][:] = g[o] * v[o][:] / ||v[o][:]||_2
+// (src/utils.py:674-675); torch: v * (g / norm(v)), its norm accumulates in fp32 (vectorised); double here, error << 1 ulp of W.
+// weights_update.hip's fold_kernel does the same arithmetic in the same order on the device.
+void fold_host(const VanerfWeightTable& w, std::vector<float>& eff)
+{
+    vanerf::LayerSrc src[NUM_LAYERS];
+    sources(w, src);
+    eff.assign(eff_offset(NUM_LAYERS), 0.0f);
+    for (int l = 0; l < NUM_LAYERS; ++l) {
+        const vanerf::LayerSrc& s = src[l];
+        float* e = eff.data() + s.eff;
+        for (int o = 0; o < s.nout; ++o) {
+            const float* v = s.w + (size_t)o * s.kin;
+            if (s.g) {
+                double sum = 0.0;
+                for (int k = 0; k < s.kin; ++k) sum += (double)v[k] * (double)v[k];
+                const float scale = s.g[o] / (float)std::sqrt(sum);
+                for (int k = 0; k < s.kin; ++k) e[(size_t)o * s.kin + k] = v[k] * scale;
+            } else {
+                for (int k = 0; k < s.kin; ++k) e[(size_t)o * s.kin + k] = v[k];
+            }
+            if (s.b) e[(size_t)s.nout * s.kin + o] = s.b[o];
+        }
     }
-    throw_error("internal: no layer %d", l);
 }
 
 // Backward stream of one layer (layer_spec.h): dX = W^T dY as the same MFMA chain with the roles swapped.  K dimension: the layer's output
@@ -250,22 +279,87 @@ void emit_bwd(std::vector<float>& out, int layer, const Mat& m, const Pairs& pai
 
 namespace vanerf {
 
+inline unsigned short bf16_rne(float f)
+{
+    unsigned u;
+    std::memcpy(&u, &f, 4);
+    return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+inline float bf16_to_f32(unsigned short b)
+{
+    unsigned u = (unsigned)b << 16;
+    float f;
+    std::memcpy(&f, &u, 4);
+    return f;
+}
+inline unsigned short bf16_part(float v, int part)
+{
+    const unsigned short hi = bf16_rne(v);
+    return part ? bf16_rne(v - bf16_to_f32(hi)) : hi;
+}
+
+// The placement tables: weight independent, built once per process.
+const PackTables& pack_tables()
+{
+    static const PackTables tables = [] {
+        PackTables t;
+        std::vector<float> fwd, bwd;
+        std::vector<WordB> fwd_b;
+        for (int l = 0; l < NUM_LAYERS; ++l) {
+            t.offs.off[l] = (unsigned)fwd.size();
+            if (fwd.size() != layer_offset(l)) throw_error("internal: layer %d starts at %zu, layer_spec.h says %u", l, fwd.size(), layer_offset(l));
+            if (fwd_b.size() != layer_offset_b(l)) throw_error("internal: layer %d (bf16x3) starts at %zu, layer_spec.h says %u", l, fwd_b.size(), layer_offset_b(l));
+            const Mat m = id_matrix(l);
+            const Pairs p = layer_pairs(l);
+            emit(fwd, l, m, p);
+            emit_b_ids(fwd_b, l, m, p);
+            emit_bwd(bwd, l, m, p);
+        }
+        // slack behind the last layer (prefetch rings never read past a layer's own steps, this is belt and braces)
+        fwd.resize(fwd.size() + 2 * 64 * 4, 0.0f);
+        bwd.resize(bwd.size() + 2 * 64 * 4, 0.0f);
+        fwd_b.resize(fwd_b.size() + 2 * 64 * 4, WordB{0, 0, 0});
+        t.fwd.assign(fwd.begin(), fwd.end());
+        t.bwd.assign(bwd.begin(), bwd.end());
+        t.fwd_b.resize(2 * fwd_b.size());
+        for (size_t i = 0; i < fwd_b.size(); ++i) {
+            t.fwd_b[2 * i] = fwd_b[i].id0 | (fwd_b[i].part << 30);
+            t.fwd_b[2 * i + 1] = fwd_b[i].id1;
+        }
+        t.n_eff = eff_offset(NUM_LAYERS);
+        for (const std::vector<int>* v : {&t.fwd, &t.bwd, &t.fwd_b})
+            for (int id : *v)
+                if ((id & 0x3fffffff) > (int)t.n_eff) throw_error("internal: placement id %d beyond the %u effective weights", id, t.n_eff);
+        return t;
+    }();
+    return tables;
+}
+
+void layer_sources(const VanerfWeightTable& w, LayerSrc out[NUM_LAYERS]) { sources(w, out); }
+
 void pack_weights_host(const VanerfWeightTable& w, std::vector<float>& out, LayerOffsets& offs, int mode, std::vector<float>* bwd)
 {
-    out.clear();
-    if (bwd) bwd->clear();
-    for (int l = 0; l < NUM_LAYERS; ++l) {
-        offs.off[l] = (unsigned)out.size();
-        const unsigned want = mode ? layer_offset_b(l) : layer_offset(l);
-        if (offs.off[l] != want) throw_error("internal: layer %d starts at %u, layer_spec.h says %u", l, offs.off[l], want);
-        const Mat m = layer_matrix(w, l);
-        const Pairs p = layer_pairs(l);
-        mode ? emit_b(out, l, m, p) : emit(out, l, m, p);
-        if (bwd) emit_bwd(*bwd, l, m, p);
+    const PackTables& t = pack_tables();
+    std::vector<float> eff;
+    fold_host(w, eff);
+    auto value = [&](int id) { return id ? eff[(size_t)id - 1] : 0.0f; };
+    for (int l = 0; l < NUM_LAYERS; ++l) offs.off[l] = mode ? layer_offset_b(l) : t.offs.off[l];
+    if (mode) {
+        const size_t n = t.fwd_b.size() / 2;
+        out.resize(n);
+        unsigned* dst = reinterpret_cast<unsigned*>(out.data());
+        for (size_t i = 0; i < n; ++i) {
+            const int a = t.fwd_b[2 * i], part = (a >> 30) & 1;
+            dst[i] = (unsigned)bf16_part(value(a & 0x3fffffff), part) | ((unsigned)bf16_part(value(t.fwd_b[2 * i + 1]), part) << 16);
+        }
+    } else {
+        out.resize(t.fwd.size());
+        for (size_t i = 0; i < out.size(); ++i) out[i] = value(t.fwd[i]);
     }
-    // slack behind the last layer (prefetch rings never read past a layer's own steps, this is belt and braces)
-    out.resize(out.size() + 2 * 64 * 4, 0.0f);
-    if (bwd) bwd->resize(bwd->size() + 2 * 64 * 4, 0.0f);
+    if (bwd) {
+        bwd->resize(t.bwd.size());
+        for (size_t i = 0; i < bwd->size(); ++i) (*bwd)[i] = value(t.bwd[i]);
+    }
 }
 
 // slot -> input channel of layer l (2 T entries, slot 2 t + h): >= 0 channel of the reference's [out][in] matrix, -1 unused, -2 bias

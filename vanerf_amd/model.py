@@ -295,24 +295,44 @@ class VANeRF(nn.Module):
 
     # ---- HIP-side state ----------------------------------------------------------------------------------------------
     def _hot_state(self):
-        return {k: v for k, v in self.state_dict().items() if not k.startswith(("geo_encoder.", "tex_encoder."))}
+        """name -> tensor of everything outside the two encoders, as state_dict() names it.  state_dict() itself walks ~3 400 entries per call
+        (1 ms, twice per training step), so the (module, name, tensor) triples are kept and only checked for replaced parameters."""
+        cache = getattr(self, "_hot_cache", None)
+        if cache is None or any(store.get(n) is not t for store, n, t, _ in cache):
+            cache = []
+            for mname, m in self.named_modules():
+                if mname.split(".")[0] in ("geo_encoder", "tex_encoder"):
+                    continue
+                prefix = mname + "." if mname else ""
+                cache += [(m._parameters, n, t, prefix + n) for n, t in m._parameters.items() if t is not None]
+                cache += [(m._buffers, n, t, prefix + n) for n, t in m._buffers.items() if t is not None and n not in m._non_persistent_buffers_set]
+            self._hot_cache = cache
+        return {k: t.detach() for _, _, t, k in cache}
+
+    def _packed_for(self, slot, precision, sd, key):
+        """The handle of `precision`, packed on first use and re-packed when a parameter changed: in place on the device when the parameters
+        live there (training: vanerf_weights_update, nothing blocks), through the host otherwise."""
+        held = getattr(self, slot, None)
+        if held is not None and held[0] == key:
+            return held[1]
+        hot = {k: v for k, v in sd.items() if k.startswith(self._PACKED_PREFIXES)}
+        if held is not None and all(v.is_cuda and v.dtype == torch.float32 and v.is_contiguous() for v in hot.values()) \
+                and held[1].device_index == next(iter(hot.values())).device.index == torch.cuda.current_device():
+            w = held[1].update(sd)
+        else:
+            w = R.PackedWeights(sd, mode=precision)
+        setattr(self, slot, (key, w))
+        return w
+
+    _PACKED_PREFIXES = ("geo_vis_fusion.", "mlp_geo.", "ibr_compress_gfeat.", "tex_vis_fusion.fconv.", "tex_vis_fusion.fconv_at.", "sigmoid_beta")
 
     def packed_weights(self, precision=None):
         """MFMA-fragment copy of the per-sample weights, re-packed whenever a parameter changed (training steps, load_state_dict).
         precision: None = the module's own; "fp32" = the handle the fused backward runs on (it carries the transposed streams)."""
-        if precision is not None and precision != self.precision:
-            sd = self._hot_state()
-            key = (precision,) + tuple((k, v._version, v.data_ptr()) for k, v in sd.items())
-            if getattr(self, "_packed_alt", None) is None or self._packed_alt[0] != key:
-                self._packed_alt = (key, R.PackedWeights(sd, mode=precision))
-            return self._packed_alt[1]
         sd = self._hot_state()
-        key = tuple((k, v._version, v.data_ptr()) for k, v in sd.items() if k.startswith(("geo_vis_fusion.", "mlp_geo.", "ibr_compress_gfeat.",
-                                                                                         "tex_vis_fusion.fconv.", "tex_vis_fusion.fconv_at.", "sigmoid_beta")))
-        key = (self.precision,) + key
-        if self._packed is None or self._packed[0] != key:
-            self._packed = (key, R.PackedWeights(sd, mode=self.precision))
-        return self._packed[1]
+        precision = precision or self.precision
+        key = (precision,) + tuple((k, v._version, v.data_ptr()) for k, v in sd.items() if k.startswith(self._PACKED_PREFIXES))
+        return self._packed_for("_packed" if precision == self.precision else "_packed_alt", precision, sd, key)
 
     def fold_transf(self, cam):
         """cam['transf'] (B,2,3): the optional 2-D affine the reference applies to every projected point, xy' = A (x/z, y/z) + t

@@ -63,12 +63,22 @@ _L1 = [(128, 358), (128, 128), (120, 136)]
 _L2 = [(64, 128), (64, 64)]
 
 
-def weight_table(sd):
-    """Reference state_dict (key names of VANeRF.state_dict()) -> (VanerfWeightTable, keep-alive list of host tensors)."""
+def weight_table(sd, on_device=False):
+    """Reference state_dict (key names of VANeRF.state_dict()) -> (VanerfWeightTable, keep-alive list of the tensors it points into).
+    on_device: the table points at the parameters' own device storage (vanerf_weights_update; no copy) instead of host copies."""
     keep = []
 
     def host(key, shape):
-        t = sd[key].detach().to("cpu", torch.float32)
+        t = sd[key].detach()
+        if on_device:
+            n = 1
+            for d in shape:
+                n *= d
+            if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.numel() == n):
+                raise ValueError(f"{key}: the device packer takes contiguous fp32 device tensors of {n} elements")
+            keep.append(t)
+            return c_void_p(t.data_ptr())
+        t = t.to("cpu", torch.float32)
         if t.dim() == 3 and t.shape[-1] == 1:
             t = t[:, :, 0]
         t = t.reshape(shape).contiguous()
@@ -84,7 +94,11 @@ def weight_table(sd):
     for i, (o, k) in enumerate(_L2):
         p = f"mlp_geo.layers2.layers.{i}.linear."
         tab.l2_v[i], tab.l2_g[i], tab.l2_b[i] = host(p + "weight_v", (o, k)), host(p + "weight_g", (o,)), host(p + "bias", (o,))
-    tab.sigmoid_beta = float(sd["sigmoid_beta"].detach().reshape(-1)[0])
+    if on_device:
+        tab.sigmoid_beta = 0.0  # taken from the device (PackedWeights.update)
+        keep.append(sd["sigmoid_beta"].detach())
+    else:
+        tab.sigmoid_beta = float(sd["sigmoid_beta"].detach().reshape(-1)[0])
     return tab, keep
 
 
@@ -107,7 +121,27 @@ class PackedWeights:
         h = c_void_p()
         check(lib.vanerf_weights_pack(byref(tab), mode, byref(h)))
         self.handle = h
-        self.beta = max(float(tab.sigmoid_beta), 2e-3)  # sdf_activation clamp (src/model.py:880)
+        self.device_index = torch.cuda.current_device() if torch.cuda.is_available() else None  # the handle lives on the device current at the pack
+        self._beta = max(float(tab.sigmoid_beta), 2e-3)  # sdf_activation clamp (src/model.py:880)
+        self._beta_src = None
+
+    @property
+    def beta(self):
+        """sigmoid_beta as the handle carries it (the per-stage debug path passes it by value; after an update on the device this read blocks)."""
+        if self._beta_src is not None:
+            self._beta = max(float(self._beta_src.reshape(-1)[0]), 2e-3)
+        return self._beta
+
+    def update(self, sd):
+        """Re-pack in place from parameters on the device (vanerf_weights_update): no host copies, nothing blocks, bit-identical to a fresh pack.
+        Ordered on the current stream after whatever still reads the old weights."""
+        tab, keep = weight_table(sd, on_device=True)
+        beta = keep[-1]
+        if not (beta.is_cuda and beta.dtype == torch.float32):
+            raise ValueError("sigmoid_beta: the device packer takes an fp32 device tensor")
+        check(lib.vanerf_weights_update(self.handle, byref(tab), c_void_p(beta.data_ptr()), _stream()))
+        self._beta_src = beta
+        return self
 
     def short_groups(self):
         """Groups of 32 samples (since packing) whose query took the all-invalid short path (blocking read; diagnostics)."""
@@ -121,6 +155,25 @@ class PackedWeights:
             self.handle = None
 
     __del__ = close
+
+
+def stream_host(sd, which):
+    """Host-only packed stream `which` (0 fp32 forward, 1 bf16x3 forward, 2 backward) as raw int32 words (tests)."""
+    tab, keep = weight_table(sd)
+    n = c_int64()
+    check(lib.vanerf_weights_stream_host(byref(tab), which, None, 0, byref(n)))
+    out = torch.empty(n.value, dtype=torch.float32)
+    check(lib.vanerf_weights_stream_host(byref(tab), which, c_void_p(out.data_ptr()), n.value, byref(n)))
+    return out.view(torch.int32)
+
+
+def stream_device(weights, which):
+    """The stream a handle holds on the device (0 forward of its mode, 2 backward), copied back, as raw int32 words (tests; blocking)."""
+    n = c_int64()
+    check(lib.vanerf_weights_download(weights.handle, which, None, 0, byref(n)))
+    out = torch.empty(n.value, dtype=torch.float32)
+    check(lib.vanerf_weights_download(weights.handle, which, c_void_p(out.data_ptr()), n.value, byref(n)))
+    return out.view(torch.int32)
 
 
 def pack_weights_host(sd):
