@@ -241,6 +241,11 @@ int vanerf_composite(const float* rgba, const float* z, const float* mesh_sdf, i
 int vanerf_composite_merged(const float* rgba_c, const float* mesh_sdf_c, int Sc, const float* rgba_n, const float* mesh_sdf_n,
                             int Sn, const int32_t* src, const float* z_fine, int R, float beta, float* color, float* depth,
                             float* alpha, float* sdf, float* contrib, void* stream);
+/* Either composite with sigmoid_beta read from the weight handle's device copy (what vanerf_render_pass does; after vanerf_weights_update the host
+ * never sees the value): rgba_n == NULL composites the Sa samples per ray of one table, otherwise [table | rgba_n table] in merged order (src).   */
+int vanerf_composite_handle(const VanerfWeights* w, const float* rgba, const float* z, const float* mesh_sdf, int Sa, const float* rgba_n,
+                            const float* mesh_sdf_n, int Sn, const int32_t* src, int R, float* color, float* depth, float* alpha, float* sdf,
+                            float* contrib, void* stream);
 
 /* a17  importance_sample + sort-merge (src/model.py:1424-1462, 1301-1307):
  *     contrib[R][Sc], z[R][Sc], u[R][Sf] (random draws) or NULL with t_lin[Sf] = th.linspace(0, 1, Sf) (uniform=True) ->
@@ -302,9 +307,11 @@ int vanerf_render_pass(const VanerfWeights* w, const VanerfFrame* frame, const V
  * src/networks.py:27-33):  table[idx[i]][0..C) += w[i] * g[i][0..C)  for i < n  (w may be NULL = 1; rows outside [0, R) are ignored).
  * All device pointers, fp32 / int32; `table` is accumulated into.  Samples outnumber rows by hundreds: the adds go through LDS-resident
  * slices of the table instead of contended global atomics.                                                                               */
-int vanerf_scatter_add_rows(const int32_t* idx, const float* w, const float* g, int64_t n, int C, float* table, int R, void* stream);
+/* g_ld: floats between consecutive rows of g (0 = C: packed rows).                                                                        */
+int vanerf_scatter_add_rows(const int32_t* idx, const float* w, const float* g, int64_t g_ld, int64_t n, int C, float* table, int R, void* stream);
 /* the same with FOUR (index, weight) pairs per sample, idx4 / w4 = [4][ld] (ld >= n): the backward of a bilinear tap gather (src/utils.py:136-151) */
-int vanerf_scatter_add_taps(const int32_t* idx4, const float* w4, int64_t ld, const float* g, int64_t n, int C, float* table, int R, void* stream);
+int vanerf_scatter_add_taps(const int32_t* idx4, const float* w4, int64_t ld, const float* g, int64_t g_ld, int64_t n, int C, float* table, int R,
+                            void* stream);
 
 /* f-4, the fused backward pass of the per-sample networks (training; reference: autograd through VANeRF.query, src/model.py:748-957, driven by
  * training_step, src/model.py:381-459).  Two launches per block of n samples, on one stream, with an fp32 weight handle (vanerf_weights_pack mode 0):
@@ -313,8 +320,9 @@ int vanerf_scatter_add_taps(const int32_t* idx4, const float* w4, int64_t ld, co
  *   vanerf_query_backward       d[n][5]: gradient with respect to eval_func's outputs [alpha, sdf, r, g, b] (src/model.py:1140-1160; d2 / noise /
  *                               noise2 may be NULL: a second set of draws on the same points, the density noise) with raw / valid of the spill pass
  *                               -> ys[y_rows][npad]: every layer's output gradient, and
- *                               ig[ig_rows][npad]: the gradients of the gathered inputs (pixel taps, nearest / twin vertex rows)
- * Channel-major fp32 spills, npad = n rounded up to a multiple of 32 (columns >= n carry zero gradients); row counts: vanerf_spill_rows.
+ *                               ig[ig_rows * npad]: the gradients of the gathered inputs (pixel taps, nearest / twin vertex rows) as nine ROW-MAJOR
+ *                               tensors [npad][stride] one after the other (vanerf_ig_tensor), which vanerf_scatter_add_rows / _taps read as they stand
+ * xs, aux, ys: channel-major fp32 spills, npad = n rounded up to a multiple of 32 (columns >= n carry zero gradients); row counts: vanerf_spill_rows.
  * The weight gradient of layer l is then one matrix product over the samples, dW'[out][slot] = ys_l xs_l^T with the rows of
  * vanerf_layer_rows and the slot -> input-channel table of vanerf_layer_slots (slot 2 t + h; -1 unused, -2 bias: that column is the bias
  * gradient); vanerf_amd/hip_backward.py does this with torch.bmm and hands ig to vanerf_scatter_add_rows.                                */
@@ -324,6 +332,10 @@ int vanerf_query_forward_spill(const VanerfWeights* w, const VanerfFrame* frame,
 int vanerf_query_backward(const VanerfWeights* w, const float* d, const float* d2, const float* noise, const float* noise2, const float* raw,
                           const uint8_t* valid, int64_t n, int64_t npad, const float* xs, const float* aux, float* ys, float* ig, void* stream);
 int vanerf_spill_rows(int* x_rows, int* y_rows, int* aux_rows, int* ig_rows);
+/* Tensor `which` of the ig spill: 0..2 pixel feature / nearest / twin vertex row of GeoVisFusion's scale 0 (64 channels), 3..5 the same of scale 1
+ * (8), 6, 7 TexVisFusion's nearest / twin vertex row [img3 | tex8 | global18] (29 of 32), 8 the texture map's pixel feature (8).  The tensor
+ * starts at ig + offset * npad, has `channels` channels and `stride` floats per row.  Returns the number of tensors (9), < 0: error.          */
+int vanerf_ig_tensor(int which, int* offset, int* channels, int* stride);
 int vanerf_layer_slots(int layer, int32_t* k_of_slot, int cap);              /* returns 2 T (k-pairs x lane halves), < 0: error */
 int vanerf_layer_rows(int layer, int* x_row, int* y_row, int* n_out);
 

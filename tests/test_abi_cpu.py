@@ -80,7 +80,7 @@ def test_backward_spill_layout_is_consistent(ffi, hot_weights):
     gathers it (once, except the duplicated pool/visibility operands), with a bias slot exactly where the reference layer has a bias."""
     from vanerf_amd import hip_backward as hb
     L = hb.layout()
-    assert (L["x_rows"], L["y_rows"], L["aux_rows"], L["ig_rows"]) == (2074, 965, 110, 286)
+    assert (L["x_rows"], L["y_rows"], L["aux_rows"], L["ig_rows"]) == (2074, 965, 110, 288)
     assert len(L["layers"]) == ffi.NUM_LAYERS == len(hb.LAYER_PARAMS)
     sd = dict(hot_weights)
     x_at = y_at = flat = 0

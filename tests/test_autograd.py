@@ -357,3 +357,34 @@ def test_steps_repack_the_weights_on_the_device():
         ((out["tex_fg_fine"] - out["tar_img"]).abs().mean() + out["alpha_fine"].mean()).backward()
         opt.step()
     assert abs(held[0].beta - max(float(net.sigmoid_beta.detach()), 2e-3)) < 1e-9
+
+
+def test_backward_chain_is_a_pure_function_of_the_sample():
+    """The fused backward processes 32-sample groups in a grid-stride loop; a sample's spilled dY and input gradients must not depend on which
+    iteration of which wave took its group.  One block of 131 072 samples (four groups per wave) against the same samples in four blocks of
+    32 768 (one group per wave), bit for bit -- a build of query_backward_kernel once restored wrong row offsets from spilled SGPRs in the second
+    and later groups of a wave (one gate's gradient 2 % off) while every test at one group per wave passed."""
+    from vanerf_amd import hip_backward as HB, renderer as R
+    n, part = 131072, 32768
+    sd = synth.make_full_weights(0)
+    frame = synth.make_frame(seed=11, tar_h=512, tar_w=334, orbit_deg=15.0)
+    fd = synth.to_device(frame, "cuda")
+    sdd = {k: v.cuda() for k, v in sd.items() if k.startswith("tex_vis_fusion.")}
+    fdat = R.FrameData(sdd, fd["img_in"], fd["feat_geo"], fd["feat_tex"], fd["src_foreground_mask"], fd["cam_in"], fd["targets"], fd["sp_data"])
+    w0 = R.PackedWeights(sd, mode="fp32")
+    rays = R.ray_setup(frame["cam_tar"], frame["bounds"], 0, 200, 1, 334, 64, 64, device="cuda")
+    pts = R.sample_points(rays["rays_d"], rays["cam_pos"], rays["z"]).view(-1, 3)[:n].contiguous()
+    q_sdf, q_vis, knn = (t.view(-1) for t in R.mesh_query_accel(fdat.accel, fdat.verts3, fdat.faces, fdat.vert_vis, pts))
+    d = torch.randn(n, 5, device="cuda", generator=torch.Generator(device="cuda").manual_seed(0))
+    ws = HB.workspace(n, pts.device)
+    ws.dw.zero_()
+    ig, _ = HB.run_block(ws, w0, fdat, pts, q_sdf, q_vis, knn, d)
+    ys_all, ig_all = ws.ys[:, :n].clone(), {k: v.clone() for k, v in ig.items()}
+    assert int(ws.valid[:n].sum()) > n // 2 and torch.isfinite(ys_all).all()
+    small = HB.Workspace(part, pts.device)
+    for b0 in range(0, n, part):
+        sl = slice(b0, b0 + part)
+        ig, _ = HB.run_block(small, w0, fdat, pts[sl], q_sdf[sl], q_vis[sl], knn[sl], d[sl])
+        assert torch.equal(small.ys[:, :part], ys_all[:, sl]), b0
+        for k, v in ig.items():
+            assert torch.equal(v, ig_all[k][sl]), (k, b0)

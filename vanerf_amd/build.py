@@ -28,11 +28,17 @@ def _stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+# query_backward_kernel once carried 1 900-3 600 spilled SGPRs (row offsets hoisted out of its group loop); the build with 3 600 restored wrong
+# offsets in the second and later groups of a wave -- 2 % off in one gate's gradient, every test at one group per wave green.  A few hundred is
+# what the chained kernels need for their constants.
+MAX_SGPR_SPILLS = 256
+
+
 def _check_no_scratch(src, remarks):
     """Every kernel of this library is written to live in registers: a build whose register allocation spills to scratch memory is a
     performance cliff that still passes every test (query_kernel once went from 0 to 59 spilled VGPRs through an innocent-looking
     change), so it fails the build.  VANERF_ALLOW_SCRATCH=1 lets experiments through."""
-    name, bad = None, []
+    name, bad, sgpr = None, [], []
     for line in remarks:
         m = re.search(r"Function Name: (\S+)", line)
         if m:
@@ -40,8 +46,14 @@ def _check_no_scratch(src, remarks):
         m = re.search(r"ScratchSize \[bytes/lane\]: (\d+)", line)
         if m and int(m.group(1)) > 0:
             bad.append((name, int(m.group(1))))
+        m = re.search(r"SGPRs Spill: (\d+)", line)
+        if m and int(m.group(1)) > MAX_SGPR_SPILLS:
+            sgpr.append((name, int(m.group(1))))
     if bad and os.environ.get("VANERF_ALLOW_SCRATCH") != "1":
         raise RuntimeError(f"{src}: kernels spill to scratch memory: {bad} (set VANERF_ALLOW_SCRATCH=1 to build anyway)")
+    if sgpr and os.environ.get("VANERF_ALLOW_SCRATCH") != "1":
+        raise RuntimeError(f"{src}: kernels spill thousands of SGPRs into VGPR lanes: {sgpr} -- loop-invariant address arithmetic hoisted out of a "
+                           "work loop; make the stride opaque per iteration (query_backward.hip) (VANERF_ALLOW_SCRATCH=1 builds anyway)")
 
 
 def build(force=False, verbose=False, extra=(), out=None):

@@ -104,9 +104,13 @@ enum AuxRow {
 };
 constexpr int AUX_ROWS = 2 * AUX_COUNT;
 // input gradients handed back to the host (gathers' backward): rows 2 t + h of
-constexpr int IG_GEO0 = 0;            // 96 slots: d [pix32 | nn32 | tw32] of scale 0 (channel = 32 h + t inside each group)
-constexpr int IG_GEO1 = 2 * 96;       // 12 slots: d [pix4 | nn4 | tw4] of scale 1
-constexpr int IG_TEX = IG_GEO1 + 24;  // 35 slots: d [vertex row 29 (h0 nearest, h1 twin) | query feature 6 (h0 q0..5, h1 q6..10)]
-constexpr int IG_ROWS = IG_TEX + 70;
+// IG spill: the gradients of the gathered inputs as ROW-MAJOR tensors [npad][C], one after the other -- what the scatter kernels read as they
+// stand (a lane holds 32 / 4 consecutive channels of its sample in consecutive registers: float4 stores).  Offsets in floats per sample
+// (x npad = offset of the tensor in the spill):
+constexpr int IG_GEO0 = 0;            // 3 x [npad][64]: d pix | d nearest vertex row | d twin vertex row of scale 0 (channel = 32 h + t)
+constexpr int IG_GEO1 = 3 * 64;       // 3 x [npad][8]: the same of scale 1 (channel = 4 h + t)
+constexpr int IG_TEX = IG_GEO1 + 24;  // 2 x [npad][32]: d vertex row [img3 | tex8 | global18 | 3 unused] of the nearest (h = 0) and the twin vertex (h = 1)
+constexpr int IG_TEX_XY = IG_TEX + 64; // [npad][8]: d texture-map pixel feature (channels 0..2 from the h = 0 lanes' slots 32..34, 3..7 from h = 1's 29..33)
+constexpr int IG_ROWS = IG_TEX_XY + 8; // floats per sample
 
 } // namespace vanerf

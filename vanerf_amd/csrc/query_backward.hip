@@ -35,7 +35,7 @@ struct BwdParams {
     const float* xs;        // [X_ROWS][npad]
     const float* aux;       // [AUX_ROWS][npad]
     float* ys;              // [Y_ROWS][npad]
-    float* ig;              // [IG_ROWS][npad]
+    float* ig;              // IG_ROWS floats per sample: row-major tensors one after the other (layer_spec.h)
 };
 
 constexpr int crow0(int reg) { return (reg & 3) + 8 * (reg >> 2); }
@@ -67,17 +67,21 @@ __global__ __launch_bounds__(BW_BLOCK, 1) void query_backward_kernel(const BwdPa
 {
     const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
     const WRsrc W = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.wb), 0, P.wbytes, 0x00020000);
-    const size_t npad = (size_t)P.npad;
     const long long ngroups = P.npad / 32, nwaves = (long long)gridDim.x * (BW_BLOCK / 64);
     for (long long g = (long long)blockIdx.x * (BW_BLOCK / 64) + (threadIdx.x >> 6); g < ngroups; g += nwaves) {
+        // the row stride, opaque per group: the ~3 000 row offsets (row x npad) of a group are loop invariants, and hoisted out of the loop they
+        // cost 1 900-3 600 spilled SGPRs (v_writelane / v_readlane around every access; one build of this kernel restored wrong offsets in the
+        // second and later groups of a wave) -- recomputed next to their use they are one s_mul each
+        size_t npad = (size_t)P.npad;
+        asm volatile("" : "+s"(npad));
         const size_t col = (size_t)g * 32 + (size_t)j;
         const float* xcol = P.xs + col + (size_t)h * npad;
         const float* acol = P.aux + col + (size_t)h * npad;
         float* ycol_h = P.ys + col + (size_t)(4 * h) * npad;
-        float* igcol = P.ig + col + (size_t)h * npad;
         auto X = [&](auto lc, auto tc) -> float { return xcol[(size_t)(x_row_base(decltype(lc)::value) + 2 * decltype(tc)::value) * npad]; };
         auto AUX = [&](auto kc) -> float { return acol[(size_t)(2 * decltype(kc)::value) * npad]; };
-        auto IG = [&](auto rc, float v) { igcol[(size_t)decltype(rc)::value * npad] = v; };
+        // IG spill: tensor at `off` floats per sample, rows of `stride` floats; this lane's sample, channel ch
+        auto IGP = [&](int off, int stride, int ch) -> float* { return P.ig + (size_t)off * npad + col * (size_t)stride + ch; };
 #define LC(l) std::integral_constant<int, (l)>{}
         auto regs = [](auto& arr) { return [&arr](auto tc) -> float { constexpr int t = decltype(tc)::value; return arr[t / 16][t % 16]; }; };
         auto relu_g = [](float x, float v) { return x > 0.0f ? v : 0.0f; };
@@ -151,7 +155,27 @@ __global__ __launch_bounds__(BW_BLOCK, 1) void query_backward_kernel(const BwdPa
             bwd_pass<L_TEX_AT_A, 0>(dx16, W, (unsigned)lane, regs(dy16));
             static_for<47>([&](auto tc) { constexpr int t = decltype(tc)::value; d_in_tex[t / 16][t % 16] += dx16[t / 16][t % 16]; });
             // vertex rows (t < 29) and query feature (29..34) go back to the host's scatters
-            static_for<35>([&](auto tc) { constexpr int t = decltype(tc)::value; IG(LC(IG_TEX + 2 * t), d_in_tex[t / 16][t % 16]); });
+            {
+                float* row = IGP(IG_TEX + 32 * h, 32, 0); // this lane half's vertex row: channels = slots 0..28
+#ifdef VANERF_EXP_IG_SCALAR_TEX
+                static_for<28>([&](auto tc) { constexpr int t = decltype(tc)::value; row[t] = d_in_tex[t / 16][t % 16]; });
+#else
+                static_for<7>([&](auto qc) {
+                    constexpr int t = 4 * decltype(qc)::value;
+                    *reinterpret_cast<float4*>(row + t) = make_float4(d_in_tex[t / 16][t % 16], d_in_tex[(t + 1) / 16][(t + 1) % 16],
+                                                                      d_in_tex[(t + 2) / 16][(t + 2) % 16], d_in_tex[(t + 3) / 16][(t + 3) % 16]);
+                });
+#endif
+                row[28] = d_in_tex[1][12];
+                float* xy = IGP(IG_TEX_XY, 8, 0);
+                // h = 0: slots 32..34 = tex 0..2 -> channels 0..2; h = 1: slots 29..33 = tex 3..7 -> channels 3..7.  Five stores from every lane, no
+                // branch (the h = 0 lanes repeat their last one)
+                static_for<5>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value, i0 = i < 2 ? i : 2;
+                    const float v1 = d_in_tex[(29 + i) / 16][(29 + i) % 16], v0 = d_in_tex[2][i0];
+                    xy[h ? 3 + i : i0] = h ? v1 : v0;
+                });
+            }
         }
         f32x16 dpool[4]; // gradient of [mean64 | var64]
         {
@@ -281,7 +305,11 @@ __global__ __launch_bounds__(BW_BLOCK, 1) void query_backward_kernel(const BwdPa
                     for (int b = 0; b < bwd_pass_blocks(LA, 1); ++b) d_in[4 + b] += pb[b];
                 }
             }
-            static_for<3 * HC>([&](auto tc) { constexpr int t = decltype(tc)::value; IG(LC(IGB + 2 * t), d_in[t / 16][t % 16]); });
+            static_for<3 * HC / 4>([&](auto qc) { // group t / HC = pix | nearest | twin; channel HC h + t % HC: four consecutive channels per store
+                constexpr int t = 4 * decltype(qc)::value;
+                *reinterpret_cast<float4*>(IGP(IGB + 2 * HC * (t / HC), 2 * HC, HC * h + t % HC)) =
+                    make_float4(d_in[t / 16][t % 16], d_in[(t + 1) / 16][(t + 1) % 16], d_in[(t + 2) / 16][(t + 2) % 16], d_in[(t + 3) / 16][(t + 3) % 16]);
+            });
         };
         {
             f32x16 dy7[1];
@@ -298,7 +326,7 @@ __global__ __launch_bounds__(BW_BLOCK, 1) void query_backward_kernel(const BwdPa
 } // namespace
 
 // The backward chain for the n samples whose forward pass vanerf_query_forward_spill has just spilled (same stream): d[n][5] (+ d2, noise draws) in,
-// Ys[Y_ROWS][npad] and IGs[IG_ROWS][npad] out (every column < npad is written).  Pure function of the spills and the weights.
+// Ys[Y_ROWS][npad] and the IG spill (IG_ROWS floats per sample, layer_spec.h) out (every column < npad is written).  Pure function of the spills and the weights.
 extern "C" int vanerf_query_backward(const VanerfWeights* w, const float* d, const float* d2, const float* noise, const float* noise2,
                                      const float* raw, const uint8_t* valid, int64_t n, int64_t npad, const float* xs, const float* aux,
                                      float* ys, float* ig, void* stream)
@@ -319,6 +347,19 @@ extern "C" int vanerf_query_backward(const VanerfWeights* w, const float* d, con
         hipLaunchKernelGGL(query_backward_kernel, dim3((unsigned)blocks), dim3(BW_BLOCK), 0, (hipStream_t)stream, P);
         HIP_CHECK(hipGetLastError());
     });
+}
+
+extern "C" int vanerf_ig_tensor(int which, int* offset, int* channels, int* stride)
+{
+    static const int tab[9][3] = {{IG_GEO0, 64, 64}, {IG_GEO0 + 64, 64, 64}, {IG_GEO0 + 128, 64, 64}, {IG_GEO1, 8, 8}, {IG_GEO1 + 8, 8, 8},
+                                  {IG_GEO1 + 16, 8, 8}, {IG_TEX, 29, 32}, {IG_TEX + 32, 29, 32}, {IG_TEX_XY, 8, 8}};
+    int rc = guarded([&] {
+        if (which < 0 || which >= 9) throw_error("vanerf_ig_tensor: tensor %d of 9", which);
+        if (offset) *offset = tab[which][0];
+        if (channels) *channels = tab[which][1];
+        if (stride) *stride = tab[which][2];
+    });
+    return rc < 0 ? rc : 9;
 }
 
 extern "C" int vanerf_spill_rows(int* x_rows, int* y_rows, int* aux_rows, int* ig_rows)

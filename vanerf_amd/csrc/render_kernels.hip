@@ -502,6 +502,20 @@ extern "C" int vanerf_composite(const float* rgba, const float* z, const float* 
     });
 }
 
+// Either composite with sigmoid_beta taken from a weight handle's device copy (what vanerf_render_pass does): rgba_n == NULL composites the
+// Sa samples of one table, otherwise the merged order of two tables as vanerf_composite_merged.
+extern "C" int vanerf_composite_handle(const VanerfWeights* w, const float* rgba, const float* z, const float* mesh_sdf, int Sa, const float* rgba_n,
+                                       const float* mesh_sdf_n, int Sn, const int32_t* src, int R, float* color, float* depth, float* alpha,
+                                       float* sdf, float* contrib, void* stream)
+{
+    return guarded([&] {
+        if (!w || !rgba || !z || !mesh_sdf || !color || !depth || !alpha || !sdf) throw_error("vanerf_composite_handle: null argument");
+        if (rgba_n && (!mesh_sdf_n || !src || Sn <= 0)) throw_error("vanerf_composite_handle: the second table needs mesh_sdf_n, src and Sn > 0");
+        vanerf::composite_with_handle(w, rgba, z, mesh_sdf, rgba_n, rgba_n ? mesh_sdf_n : nullptr, rgba_n ? src : nullptr, Sa, rgba_n ? Sn : 0, R, color,
+                                      depth, alpha, sdf, contrib, stream);
+    });
+}
+
 extern "C" int vanerf_composite_merged(const float* rgba_c, const float* mesh_sdf_c, int Sc, const float* rgba_n, const float* mesh_sdf_n,
                                        int Sn, const int32_t* src, const float* z_fine, int R, float beta, float* color, float* depth,
                                        float* alpha, float* sdf, float* contrib, void* stream)

@@ -19,7 +19,7 @@ constexpr int SC_BLOCK = 256;
 // TAPS rows per sample (idx / w are [TAPS][ld]): the four bilinear taps of a pixel feature read its gradient row once
 template <int CS, int TAPS = 1>
 __global__ __launch_bounds__(SC_BLOCK) void scatter_rows_kernel(const int32_t* __restrict__ idx, const float* __restrict__ w, const float* __restrict__ g,
-                                                                long long n, int C, int R, float* __restrict__ table, long long ld = 0)
+                                                                long long n, int C, int R, float* __restrict__ table, long long ld, long long g_ld)
 {
     extern __shared__ float s_tab[];
     const int c0 = blockIdx.y * CS;
@@ -32,7 +32,7 @@ __global__ __launch_bounds__(SC_BLOCK) void scatter_rows_kernel(const int32_t* _
     const long long i0 = (long long)blockIdx.x * chunk, i1 = i0 + chunk < n ? i0 + chunk : n;
     if (c0 + cl < C)
         for (long long i = i0 + sub; i < i1; i += PER) {
-            const float v0 = g[i * C + c0 + cl];
+            const float v0 = g[i * g_ld + c0 + cl];
 #pragma unroll
             for (int k = 0; k < TAPS; ++k) {
                 const int r = idx[i + k * ld];
@@ -55,32 +55,37 @@ __global__ __launch_bounds__(SC_BLOCK) void scatter_rows_kernel(const int32_t* _
 // table[R][C] += scatter of w[i] * g[i][C] at rows idx[i] (w may be NULL = 1).  All device pointers; `table` is accumulated into (zero it first
 // for a plain gradient).  Rows outside [0, R) are ignored.
 namespace {
-void scatter_rows(const int32_t* idx, const float* w, const float* g, int64_t n, int C, float* table, int R, int taps, int64_t ld, void* stream);
+void scatter_rows(const int32_t* idx, const float* w, const float* g, int64_t g_ld, int64_t n, int C, float* table, int R, int taps, int64_t ld,
+                  void* stream);
 }
 
-extern "C" int vanerf_scatter_add_rows(const int32_t* idx, const float* w, const float* g, int64_t n, int C, float* table, int R, void* stream)
+extern "C" int vanerf_scatter_add_rows(const int32_t* idx, const float* w, const float* g, int64_t g_ld, int64_t n, int C, float* table, int R,
+                                       void* stream)
 {
-    return guarded([&] { scatter_rows(idx, w, g, n, C, table, R, 1, 0, stream); });
+    return guarded([&] { scatter_rows(idx, w, g, g_ld, n, C, table, R, 1, 0, stream); });
 }
 
 // the same with FOUR (index, weight) pairs per sample, idx4 / w4 = [4][ld] (ld >= n): table[idx4[k][i]] += w4[k][i] * g[i] for k < 4 -- the
 // backward of a bilinear tap gather (src/utils.py:136-151) in one launch that reads every gradient row once
-extern "C" int vanerf_scatter_add_taps(const int32_t* idx4, const float* w4, int64_t ld, const float* g, int64_t n, int C, float* table, int R,
-                                       void* stream)
+extern "C" int vanerf_scatter_add_taps(const int32_t* idx4, const float* w4, int64_t ld, const float* g, int64_t g_ld, int64_t n, int C, float* table,
+                                       int R, void* stream)
 {
     return guarded([&] {
         if (ld < n || !w4) throw_error("vanerf_scatter_add_taps: ld = %lld < n = %lld or no weights", (long long)ld, (long long)n);
-        scatter_rows(idx4, w4, g, n, C, table, R, 4, ld, stream);
+        scatter_rows(idx4, w4, g, g_ld, n, C, table, R, 4, ld, stream);
     });
 }
 
 namespace {
-void scatter_rows(const int32_t* idx, const float* w, const float* g, int64_t n, int C, float* table, int R, int taps, int64_t ld, void* stream)
+void scatter_rows(const int32_t* idx, const float* w, const float* g, int64_t g_ld, int64_t n, int C, float* table, int R, int taps, int64_t ld,
+                  void* stream)
 {
     {
         if (n == 0) return;
         if (!idx || !g || !table) throw_error("vanerf_scatter_add_rows: null argument");
         if (n < 0 || C <= 0 || R <= 0) throw_error("vanerf_scatter_add_rows: n=%lld C=%d R=%d", (long long)n, C, R);
+        if (g_ld == 0) g_ld = C;
+        if (g_ld < C) throw_error("vanerf_scatter_add_rows: rows of %d channels, %lld floats apart", C, (long long)g_ld);
         // channel slice: the widest power of two <= 16 whose [R][CS] floats fit 128 KB of LDS
         int cs = 16;
         while (cs > 1 && ((size_t)R * cs * 4 > 128 * 1024 || cs / 2 >= C)) cs /= 2;
@@ -99,7 +104,7 @@ void scatter_rows(const int32_t* idx, const float* w, const float* g, int64_t n,
 #define LAUNCH1(CS, TAPS)                                                                                                                  \
     do {                                                                                                                                   \
         if (lds > 64 * 1024) HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(scatter_rows_kernel<CS, TAPS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL((scatter_rows_kernel<CS, TAPS>), grid, dim3(SC_BLOCK), lds, st, idx, w, g, (long long)n, C, R, table, (long long)ld); \
+        hipLaunchKernelGGL((scatter_rows_kernel<CS, TAPS>), grid, dim3(SC_BLOCK), lds, st, idx, w, g, (long long)n, C, R, table, (long long)ld, (long long)g_ld); \
     } while (0)
 #define LAUNCH(CS) do { if (taps == 4) LAUNCH1(CS, 4); else LAUNCH1(CS, 1); } while (0)
         switch (cs) {

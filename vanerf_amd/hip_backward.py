@@ -55,7 +55,13 @@ def layout():
             layers.append({"x_row": xr.value, "y_row": yr.value, "n_out": no.value, "n_slots": n_slots, "slots": torch.tensor(list(buf), dtype=torch.long),
                            "flat": at})
             at += no.value * n_slots
-        _LAYOUT = {"x_rows": rows[0].value, "y_rows": rows[1].value, "aux_rows": rows[2].value, "ig_rows": rows[3].value, "layers": layers, "flat": at}
+        ig = []
+        for which in range(9):
+            o, c, st = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+            check(min(0, lib.vanerf_ig_tensor(which, ctypes.byref(o), ctypes.byref(c), ctypes.byref(st))))
+            ig.append((o.value, c.value, st.value))
+        _LAYOUT = {"x_rows": rows[0].value, "y_rows": rows[1].value, "aux_rows": rows[2].value, "ig_rows": rows[3].value, "layers": layers, "flat": at,
+                   "ig": dict(zip(("pix0", "nn0", "tw0", "pix1", "nn1", "tw1", "row_nn", "row_tw", "tex_xy"), ig))}
     return _LAYOUT
 
 
@@ -73,7 +79,7 @@ class Workspace:
         self.xs = torch.empty(L["x_rows"], npad, dtype=f32, device=device)
         self.aux = torch.empty(L["aux_rows"], npad, dtype=f32, device=device)
         self.ys = torch.empty(L["y_rows"], npad, dtype=f32, device=device)
-        self.ig = torch.empty(L["ig_rows"], npad, dtype=f32, device=device)
+        self.ig = torch.empty(L["ig_rows"] * npad, dtype=f32, device=device)  # nine row-major tensors, one after the other (vanerf_ig_tensor)
         self.raw = torch.empty(npad, 5, dtype=f32, device=device)
         self.valid = torch.empty(npad, dtype=torch.uint8, device=device)
         # weight-gradient accumulators: per layer (SLICES, n_out, n_slots), summed over the slices once per step (parameter_gradients)
@@ -89,14 +95,15 @@ class Workspace:
 def run_block(ws, w0, fdat, pts, q_sdf, q_vis, knn, d, noise=None, d2=None, noise2=None):
     """One block of n samples: forward spill, eval_func's derivative, backward chain, weight products.  d, d2: (n, 5) gradients with respect to
     eval_func's outputs [alpha, sdf, r, g, b] (d2 / noise2: the second set of draws the coarse points carry inside the fine batch, or None).
-    Returns the block's input gradients (views into the workspace, valid until the next block)."""
+    Returns the block's input gradients (input_gradients(): views into the workspace, valid until the next block) and n."""
     n = pts.shape[0]
     npad = (n + 31) // 32 * 32
     assert npad <= ws.block
     st = R._stream()
-    xs, aux, ys, ig = (t[:, :npad] if npad == ws.block else None for t in (ws.xs, ws.aux, ws.ys, ws.ig))
+    xs, aux, ys = (t[:, :npad] if npad == ws.block else None for t in (ws.xs, ws.aux, ws.ys))
     if npad != ws.block:  # a shorter last block: compact spills of its own width (the kernels address rows with stride npad)
-        xs, aux, ys, ig = (t.view(-1)[:t.shape[0] * npad].view(t.shape[0], npad) for t in (ws.xs, ws.aux, ws.ys, ws.ig))
+        xs, aux, ys = (t.view(-1)[:t.shape[0] * npad].view(t.shape[0], npad) for t in (ws.xs, ws.aux, ws.ys))
+    ig = ws.ig
     check(lib.vanerf_query_forward_spill(w0.handle, ctypes.byref(fdat.c), _ptr(pts), _ptr(q_sdf), _ptr(q_vis), _ptr(knn), n, npad, _ptr(ws.raw),
                                          _ptr(ws.valid), _ptr(xs), _ptr(aux), _ptr(R._queue_word(pts.device)), st))
     c = lambda t: None if t is None else t.reshape(-1).contiguous() if t.dim() == 1 or t.shape[-1] != 5 else t.contiguous()
@@ -104,7 +111,7 @@ def run_block(ws, w0, fdat, pts, q_sdf, q_vis, knn, d, noise=None, d2=None, nois
     check(lib.vanerf_query_backward(w0.handle, _ptr(d), _ptr(d2), _ptr(noise), _ptr(noise2), _ptr(ws.raw), _ptr(ws.valid), n, npad, _ptr(xs),
                                     _ptr(aux), _ptr(ys), _ptr(ig), st))
     _weight_products_on(ws, xs, ys, npad)
-    return ig, n
+    return input_gradients(ig, n, npad), n
 
 
 def _weight_products_on(ws, xs, ys, npad):
@@ -168,17 +175,11 @@ def parameter_gradients(ws, P):
     return out
 
 
-def input_gradients(ig, n):
-    """The block's IG spill -> row-major gradients of the gathered inputs: dict of (n, C) tensors.
+def input_gradients(ig, n, npad):
+    """The block's IG spill -> the gradients of the gathered inputs: dict of (n, C) views (no copies; rows `stride` floats apart).
     pix0 / nn0 / tw0 (64), pix1 / nn1 / tw1 (8): GeoVisFusion's pixel feature, nearest and twin vertex rows of both scales;
     row_nn / row_tw (29): TexVisFusion's vertex rows [img3 | tex8 | global18]; tex_xy (8): the texture map's pixel feature."""
-    g0 = ig[0:192, :n].view(3, 32, 2, n).permute(0, 2, 1, 3).reshape(3, 64, n)   # channel = 32 h + t inside each group
-    g1 = ig[192:216, :n].view(3, 4, 2, n).permute(0, 2, 1, 3).reshape(3, 8, n)
-    tx = ig[216:286, :n].view(35, 2, n)
-    out = {"pix0": g0[0].t(), "nn0": g0[1].t(), "tw0": g0[2].t(), "pix1": g1[0].t(), "nn1": g1[1].t(), "tw1": g1[2].t(),
-           "row_nn": tx[:29, 0].t(), "row_tw": tx[:29, 1].t(),
-           "tex_xy": torch.cat([tx[32:35, 0], tx[29:34, 1]], 0).t()}  # h0: q0..5 = [img 0..2 | tex 0..2], h1: q6..10 = tex 3..7
-    return {k: v.contiguous() for k, v in out.items()}
+    return {k: ig[o * npad:(o + st) * npad].view(npad, st)[:n, :c] for k, (o, c, st) in layout()["ig"].items()}
 
 
 _WS = {}

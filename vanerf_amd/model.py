@@ -564,7 +564,8 @@ class VANeRF(nn.Module):
         from . import torch_graph as G
         o, fd, cam_in = self._last_pass
         self._last_pass = (o, fd, cam_in) if getattr(self, "_keep_last_pass", False) else None  # tests inspect the pass
-        named = [(k, p) for k, p in self.named_parameters() if not k.startswith(("geo_encoder.", "tex_encoder.", "mlp_tex."))]
+        self._hot_state()  # (refreshes the kept list; named_parameters() walks the encoders' ~1 700 entries too: 1 ms per step)
+        named = [(k, t) for _, _, t, k in self._hot_cache if isinstance(t, nn.Parameter) and not k.startswith("mlp_tex.")]
         names = [k for k, _ in named] + ["@feat_geo0", "@feat_geo1", "@feat_tex"]
         leaves = [p for _, p in named] + [feat_geo[0], feat_geo[1], feat_tex]
         frame = {"cam": cam_in, "img": img_in, "fg_mask": fg_mask.reshape(1, 1, *fg_mask.shape[-2:]), "verts": targets["vert_world"][0],

@@ -430,14 +430,19 @@ def query_samples(weights, frame, pts, query_sdf, query_vis, knn_idx, noise=None
 
 
 def composite(rgba, z, mesh_sdf, beta, want_contrib=True):
-    """sdf_activation + rgba2out (src/model.py:879-882, 1464-1494).  rgba (R,S,5), z (R,S), mesh_sdf (R,S)."""
+    """sdf_activation + rgba2out (src/model.py:879-882, 1464-1494).  rgba (R,S,5), z (R,S), mesh_sdf (R,S).
+    beta: a number, or the PackedWeights whose device copy of sigmoid_beta the kernel reads (no host value involved)."""
     R, S = z.shape
     dev = z.device
     color = torch.empty(R, 3, dtype=torch.float32, device=dev)
     depth, alpha, sdf = (torch.empty(R, dtype=torch.float32, device=dev) for _ in range(3))
     contrib = torch.empty(R, S, dtype=torch.float32, device=dev) if want_contrib else None
-    check(lib.vanerf_composite(_ptr(rgba, torch.float32), _ptr(z, torch.float32), _ptr(mesh_sdf, torch.float32), R, S, float(beta),
-                               _ptr(color), _ptr(depth), _ptr(alpha), _ptr(sdf), _ptr(contrib), _stream()))
+    if isinstance(beta, PackedWeights):
+        check(lib.vanerf_composite_handle(beta.handle, _ptr(rgba, torch.float32), _ptr(z, torch.float32), _ptr(mesh_sdf, torch.float32), S, None, None, 0,
+                                          None, R, _ptr(color), _ptr(depth), _ptr(alpha), _ptr(sdf), _ptr(contrib), _stream()))
+    else:
+        check(lib.vanerf_composite(_ptr(rgba, torch.float32), _ptr(z, torch.float32), _ptr(mesh_sdf, torch.float32), R, S, float(beta),
+                                   _ptr(color), _ptr(depth), _ptr(alpha), _ptr(sdf), _ptr(contrib), _stream()))
     return color, depth, alpha, contrib, sdf
 
 
@@ -450,9 +455,14 @@ def composite_merged(rgba_c, sdf_c, rgba_n, sdf_n, src, z_fine, beta, want_contr
     color = torch.empty(R, 3, dtype=torch.float32, device=dev)
     depth, alpha, sdf = (torch.empty(R, dtype=torch.float32, device=dev) for _ in range(3))
     contrib = torch.empty(R, S, dtype=torch.float32, device=dev) if want_contrib else None
-    check(lib.vanerf_composite_merged(_ptr(rgba_c, torch.float32), _ptr(sdf_c, torch.float32), Sc, _ptr(rgba_n, torch.float32),
-                                      _ptr(sdf_n, torch.float32), Sn, _ptr(src, torch.int32), _ptr(z_fine, torch.float32), R, float(beta),
-                                      _ptr(color), _ptr(depth), _ptr(alpha), _ptr(sdf), _ptr(contrib), _stream()))
+    if isinstance(beta, PackedWeights):
+        check(lib.vanerf_composite_handle(beta.handle, _ptr(rgba_c, torch.float32), _ptr(z_fine, torch.float32), _ptr(sdf_c, torch.float32), Sc,
+                                          _ptr(rgba_n, torch.float32), _ptr(sdf_n, torch.float32), Sn, _ptr(src, torch.int32), R,
+                                          _ptr(color), _ptr(depth), _ptr(alpha), _ptr(sdf), _ptr(contrib), _stream()))
+    else:
+        check(lib.vanerf_composite_merged(_ptr(rgba_c, torch.float32), _ptr(sdf_c, torch.float32), Sc, _ptr(rgba_n, torch.float32),
+                                          _ptr(sdf_n, torch.float32), Sn, _ptr(src, torch.int32), _ptr(z_fine, torch.float32), R, float(beta),
+                                          _ptr(color), _ptr(depth), _ptr(alpha), _ptr(sdf), _ptr(contrib), _stream()))
     return color, depth, alpha, contrib, sdf
 
 
@@ -663,7 +673,7 @@ def render_pass(weights, frame, cam_tar, bounds, x0, y0, step, nx, ny, sample_pe
         c["rgba"] = eval_func(c["raw"], c["valid"], c["noise"]).view(R, Sc, 5)
     else:
         c = evaluate(rays["z"], None if noise_draws is None else noise_draws[0])
-    c["color"], c["depth"], c["alpha"], c["contrib"], c["sdf"] = composite(c["rgba"], rays["z"], c["q_sdf"], weights.beta)
+    c["color"], c["depth"], c["alpha"], c["contrib"], c["sdf"] = composite(c["rgba"], rays["z"], c["q_sdf"], weights)
     out = {"color": c["color"], "depth": c["depth"], "alpha": c["alpha"], "index": rays["index"], "z": rays["z"], "hit": rays["hit"],
            "rays_d": rays["rays_d"], "cam_pos": rays["cam_pos"]}
     if debug:
@@ -687,14 +697,14 @@ def render_pass(weights, frame, cam_tar, bounds, x0, y0, step, nx, ny, sample_pe
             cf = {"noise": noise_f.gather(1, pos[:, :Sc]).reshape(-1).contiguous()}  # the coarse points as the fine batch sees them
             cf["rgba"] = eval_func(c["raw"], c["valid"], cf["noise"]).view(R, Sc, 5)
             f["color"], f["depth"], f["alpha"], f["contrib"], f["sdf"] = composite_merged(cf["rgba"], c["q_sdf"], f["rgba"], f["q_sdf"], src,
-                                                                                          z_fine, weights.beta, want_contrib=debug)
+                                                                                          z_fine, weights, want_contrib=debug)
         elif reuse_coarse:
             f = evaluate(z_new)
             f["color"], f["depth"], f["alpha"], f["contrib"], f["sdf"] = composite_merged(c["rgba"], c["q_sdf"], f["rgba"], f["q_sdf"], src,
-                                                                                          z_fine, weights.beta, want_contrib=debug)
+                                                                                          z_fine, weights, want_contrib=debug)
         else:
             f = evaluate(z_fine, None if noise_draws is None else noise_draws[1])
-            f["color"], f["depth"], f["alpha"], f["contrib"], f["sdf"] = composite(f["rgba"], z_fine, f["q_sdf"], weights.beta, want_contrib=debug)
+            f["color"], f["depth"], f["alpha"], f["contrib"], f["sdf"] = composite(f["rgba"], z_fine, f["q_sdf"], weights, want_contrib=debug)
         out.update({"color_fine": f["color"], "depth_fine": f["depth"], "alpha_fine": f["alpha"], "sdf": f["sdf"], "z_fine": z_fine, "z_new": z_new})
         if debug:
             out["fine"] = f
@@ -749,6 +759,17 @@ def render_pass_c(weights, frame, cam_tar, bounds, x0, y0, step, nx, ny, sample_
     return out
 
 
+def _rows(g):
+    """(n, C) with unit stride along the channels and rows any distance >= C apart (a column slice of a wider row-major tensor) is read in place."""
+    return g if g.dim() == 2 and g.stride(1) == 1 and g.stride(0) >= g.shape[1] else g.contiguous()
+
+
+def _rows_ptr(g):
+    if not (g.is_cuda and g.dtype == torch.float32 and g.dim() == 2 and g.stride(1) == 1):
+        raise ValueError("rows of fp32 channels on the device")
+    return ctypes.c_void_p(g.data_ptr())
+
+
 def scatter_add_taps(table, idx4, w4, sl, g):
     """table[idx4[k][i]] += w4[k][i] * g[i - sl.start] for the samples i of slice `sl`, k < 4 (vanerf_scatter_add_taps): idx4 (4, N) int32, w4 (4, N)."""
     n, C = g.shape
@@ -757,8 +778,9 @@ def scatter_add_taps(table, idx4, w4, sl, g):
         for k in range(4):
             table.index_add_(0, idx4[k, sl].long(), g * w4[k, sl].reshape(-1, 1))
         return table
+    g = _rows(g)
     check(lib.vanerf_scatter_add_taps(ctypes.c_void_p(idx4.data_ptr() + 4 * sl.start), ctypes.c_void_p(w4.data_ptr() + 4 * sl.start), idx4.shape[1],
-                                      _ptr(g.contiguous(), torch.float32), n, C, _ptr(table, torch.float32), table.shape[0], _stream()))
+                                      _rows_ptr(g), g.stride(0), n, C, _ptr(table, torch.float32), table.shape[0], _stream()))
     return table
 
 
@@ -769,6 +791,7 @@ def scatter_add_rows(table, idx, g, w=None):
     if table.shape[0] * 4 > 128 * 1024:  # a table of more than 32 768 rows (a feature map beyond 181 x 181) does not fit the kernel's LDS slice
         table.index_add_(0, idx.long(), g if w is None else g * w.reshape(-1, 1))
         return table
-    check(lib.vanerf_scatter_add_rows(_ptr(idx, torch.int32), _ptr(w, torch.float32), _ptr(g.contiguous(), torch.float32), n, C,
+    g = _rows(g)
+    check(lib.vanerf_scatter_add_rows(_ptr(idx, torch.int32), _ptr(w, torch.float32), _rows_ptr(g), g.stride(0), n, C,
                                       _ptr(table, torch.float32), table.shape[0], _stream()))
     return table

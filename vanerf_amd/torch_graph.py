@@ -16,6 +16,8 @@ import math
 import torch
 import torch.nn.functional as F
 
+from .renderer import _avg_pool3
+
 NUM_V = 779  # vertices per hand: the "other hand" twin of vertex i is (i + 779) mod 1558 (src/networks.py:30-32)
 
 
@@ -221,7 +223,7 @@ def texture_vertex_table(P, vert_xy, feat_tex, img, pre="tex_vis_fusion."):
         x = torch.relu(F.layer_norm(x, [hw, hw], P[pre + name + ".1.weight"], P[pre + name + ".1.bias"], 1e-6))
         x = F.conv2d(x, P[pre + name + ".3.weight"], padding=1)
         x = torch.relu(F.layer_norm(x, [hw, hw], P[pre + name + ".4.weight"], P[pre + name + ".4.bias"], 1e-6))
-        return F.adaptive_avg_pool2d(x, 3).reshape(1, x.shape[1], 9)
+        return _avg_pool3(x).reshape(1, x.shape[1], 9)  # AdaptiveAvgPool2d(3) as two small products (renderer._avg_pool3; differentiable)
 
     gf = torch.cat([stack(img, "fconv4"), stack(feat_tex, "fconv3")], -1)  # (1, NV, 18): the conv stacks have NV output channels
     x = F.conv1d(gf, P[pre + "fconv_gt.0.weight"], padding=1)
@@ -558,7 +560,7 @@ class PassGradient(torch.autograd.Function):
                             sl = slice(b0, min(n_all, b0 + blk))
                             ig, nb = HB.run_block(ws, hb["w0"], hb["fdat"], pts_a[sl], qs_a[sl], qv_a[sl], knn_a[sl], d_a[sl],
                                                   None if nz_a is None else nz_a[sl], None if d2_a is None else d2_a[sl], None if nz2_a is None else nz2_a[sl])
-                            hip_state["scatter"].add(sl, HB.input_gradients(ig, nb))
+                            hip_state["scatter"].add(sl, ig)
                     mark("fused backward blocks")
                     continue
                 block = spec.get("samples_per_block") or n_all
