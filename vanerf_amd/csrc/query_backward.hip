@@ -50,15 +50,27 @@ __device__ __forceinline__ void bwd_pass(f32x16 (&acc)[bwd_pass_blocks(L, P)], W
     run_layer<NB, T>(acc, ring, rs, bwd_pass_offset(L, P), lane * NB * 4u, static_cast<Op&&>(dy));
 }
 
-// the layer's output gradient, row by row, into Ys (what the weight gradient's matrix product reads).  ycol_h = ys + column + 4 h npad.
-template <int L, class Op> __device__ __forceinline__ void store_dy(Op&& dy, float* ycol_h, size_t npad, int h)
+// Spill addressing: buffer instructions, offset = the lane's column (VGPR) + a wave-uniform row offset (row x 4 npad, one s_mul) -- global
+// accesses with 64-bit addresses took ~4 extra instructions each (13.1 k instructions per group).  A lane that must not store holds the
+// column NO_COL: beyond the buffer's size, the hardware drops the store.
+constexpr unsigned NO_COL = 0xfffffff0u;
+struct Spills {
+    WRsrc xs, aux, ys, ig;
+    unsigned row4;            // bytes per row of the channel-major spills: 4 npad
+    unsigned vx;              // xs / aux: 4 (col + h npad)
+    unsigned vy, vy0;         // ys: 4 (col + 4 h npad); the same for the h = 0 lanes only
+    unsigned col;             // the sample's column
+};
+
+// the layer's output gradient, row by row, into Ys (what the weight gradient's matrix product reads)
+template <int L, class Op> __device__ __forceinline__ void store_dy(Op&& dy, const Spills& S)
 {
     static_for<kBT[L]>([&](auto tc) {
         constexpr int t = decltype(tc)::value, row_a = 32 * (t / 16) + crow0(t % 16);
         if constexpr (row_a < kNOUT[L]) {
             const float v = dy(tc);
-            if constexpr (row_a + 4 < kNOUT[L]) ycol_h[(size_t)(y_row_base(L) + row_a) * npad] = v;
-            else if (h == 0) ycol_h[(size_t)(y_row_base(L) + row_a) * npad] = v;
+            // rows row_a (h = 0) and row_a + 4 (h = 1); the last rows of a layer exist in the h = 0 lanes only
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), S.ys, (row_a + 4 < kNOUT[L]) ? S.vy : S.vy0, (unsigned)(y_row_base(L) + row_a) * S.row4, 0);
         }
     });
 }
@@ -68,6 +80,11 @@ __global__ __launch_bounds__(BW_BLOCK, 1) void query_backward_kernel(const BwdPa
     const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
     const WRsrc W = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.wb), 0, P.wbytes, 0x00020000);
     const long long ngroups = P.npad / 32, nwaves = (long long)gridDim.x * (BW_BLOCK / 64);
+    // the four spills as buffers of their exact sizes (the host checks that the largest stays below 4 GB)
+    const WRsrc xs_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.xs), 0, (unsigned)(X_ROWS * 4ll * P.npad), 0x00020000);
+    const WRsrc aux_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.aux), 0, (unsigned)(AUX_ROWS * 4ll * P.npad), 0x00020000);
+    const WRsrc ys_rs = __builtin_amdgcn_make_buffer_rsrc(P.ys, 0, (unsigned)(Y_ROWS * 4ll * P.npad), 0x00020000);
+    const WRsrc ig_rs = __builtin_amdgcn_make_buffer_rsrc(P.ig, 0, (unsigned)(IG_ROWS * 4ll * P.npad), 0x00020000);
     for (long long g = (long long)blockIdx.x * (BW_BLOCK / 64) + (threadIdx.x >> 6); g < ngroups; g += nwaves) {
         // the row stride, opaque per group: the ~3 000 row offsets (row x npad) of a group are loop invariants, and hoisted out of the loop they
         // cost 1 900-3 600 spilled SGPRs (v_writelane / v_readlane around every access; one build of this kernel restored wrong offsets in the
@@ -75,13 +92,27 @@ __global__ __launch_bounds__(BW_BLOCK, 1) void query_backward_kernel(const BwdPa
         size_t npad = (size_t)P.npad;
         asm volatile("" : "+s"(npad));
         const size_t col = (size_t)g * 32 + (size_t)j;
-        const float* xcol = P.xs + col + (size_t)h * npad;
-        const float* acol = P.aux + col + (size_t)h * npad;
-        float* ycol_h = P.ys + col + (size_t)(4 * h) * npad;
-        auto X = [&](auto lc, auto tc) -> float { return xcol[(size_t)(x_row_base(decltype(lc)::value) + 2 * decltype(tc)::value) * npad]; };
-        auto AUX = [&](auto kc) -> float { return acol[(size_t)(2 * decltype(kc)::value) * npad]; };
-        // IG spill: tensor at `off` floats per sample, rows of `stride` floats; this lane's sample, channel ch
-        auto IGP = [&](int off, int stride, int ch) -> float* { return P.ig + (size_t)off * npad + col * (size_t)stride + ch; };
+        Spills S;
+        S.xs = xs_rs; S.aux = aux_rs; S.ys = ys_rs; S.ig = ig_rs;
+        S.row4 = (unsigned)npad * 4u;
+        S.col = (unsigned)col;
+        S.vx = 4u * (unsigned)col + (unsigned)h * S.row4;
+        S.vy = 4u * (unsigned)col + (unsigned)(4 * h) * S.row4;
+        S.vy0 = h ? NO_COL : S.vy;
+        auto X = [&](auto lc, auto tc) -> float {
+            return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(S.xs, S.vx, (unsigned)(x_row_base(decltype(lc)::value) + 2 * decltype(tc)::value) * S.row4, 0));
+        };
+        auto AUX = [&](auto kc) -> float { return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(S.aux, S.vx, (unsigned)(2 * decltype(kc)::value) * S.row4, 0)); };
+        // IG spill: tensor at `off` floats per sample (x npad: wave-uniform), rows of `stride` floats; this lane's sample, channel ch
+        auto IG1 = [&](int off, int stride, int ch, float v) {
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), S.ig, 4u * (S.col * (unsigned)stride + (unsigned)ch), (unsigned)off * S.row4, 0);
+        };
+        auto IG4 = [&](int off, int stride, int ch, float a, float b, float c, float dd) {
+            const u32x4 q = {__float_as_uint(a), __float_as_uint(b), __float_as_uint(c), __float_as_uint(dd)};
+            // (the whole offset in the VGPR: a 16-byte buffer store with an SGPR offset reads its data late, and the compiler put a v_pk_mov_b32
+            // into the data registers right behind one -- lanes 12..15 / 28..31 of one channel stored the NEXT value, differently from run to run)
+            __builtin_amdgcn_raw_buffer_store_b128(q, S.ig, 4u * (S.col * (unsigned)stride + (unsigned)ch) + (unsigned)off * S.row4, 0, 0);
+        };
 #define LC(l) std::integral_constant<int, (l)>{}
         auto regs = [](auto& arr) { return [&arr](auto tc) -> float { constexpr int t = decltype(tc)::value; return arr[t / 16][t % 16]; }; };
         auto relu_g = [](float x, float v) { return x > 0.0f ? v : 0.0f; };
@@ -108,12 +139,12 @@ __global__ __launch_bounds__(BW_BLOCK, 1) void query_backward_kernel(const BwdPa
             f32x16 dy19[1];
             zero<1>(dy19);
             dy19[0][0] = d_out[2]; dy19[0][1] = d_out[3]; dy19[0][2] = d_out[4];
-            store_dy<L_TEX_B>(regs(dy19), ycol_h, npad, h);
+            store_dy<L_TEX_B>(regs(dy19), S);
             f32x16 dx19[3];
             bwd_pass<L_TEX_B, 0>(dx19, W, (unsigned)lane, regs(dy19));
             f32x16 dy18[3];
             static_for<48>([&](auto tc) { constexpr int t = decltype(tc)::value; dy18[t / 16][t % 16] = relu_g(X(LC(L_TEX_B), tc), dx19[t / 16][t % 16]); });
-            store_dy<L_TEX_A>(regs(dy18), ycol_h, npad, h);
+            store_dy<L_TEX_A>(regs(dy18), S);
             f32x16 dx18[3]; // gradient of the GATED input
             bwd_pass<L_TEX_A, 0>(dx18, W, (unsigned)lane, regs(dy18));
             // gates (src/networks.py:287-290): products input x gate; the lane half's gates come from the auxiliary spill as it used them
@@ -145,35 +176,32 @@ __global__ __launch_bounds__(BW_BLOCK, 1) void query_backward_kernel(const BwdPa
                 dy17[0][2] = h ? 0.0f : dsig(g11_o, o_11);
                 dy17[0][3] = h ? 0.0f : dsig(ggf, s_gf);
             }
-            store_dy<L_TEX_AT_B>(regs(dy17), ycol_h, npad, h);
+            store_dy<L_TEX_AT_B>(regs(dy17), S);
             f32x16 dx17[3];
             bwd_pass<L_TEX_AT_B, 0>(dx17, W, (unsigned)lane, regs(dy17));
             f32x16 dy16[3];
             static_for<48>([&](auto tc) { constexpr int t = decltype(tc)::value; dy16[t / 16][t % 16] = relu_g(X(LC(L_TEX_AT_B), tc), dx17[t / 16][t % 16]); });
-            store_dy<L_TEX_AT_A>(regs(dy16), ycol_h, npad, h);
+            store_dy<L_TEX_AT_A>(regs(dy16), S);
             f32x16 dx16[3];
             bwd_pass<L_TEX_AT_A, 0>(dx16, W, (unsigned)lane, regs(dy16));
             static_for<47>([&](auto tc) { constexpr int t = decltype(tc)::value; d_in_tex[t / 16][t % 16] += dx16[t / 16][t % 16]; });
             // vertex rows (t < 29) and query feature (29..34) go back to the host's scatters
             {
-                float* row = IGP(IG_TEX + 32 * h, 32, 0); // this lane half's vertex row: channels = slots 0..28
-#ifdef VANERF_EXP_IG_SCALAR_TEX
-                static_for<28>([&](auto tc) { constexpr int t = decltype(tc)::value; row[t] = d_in_tex[t / 16][t % 16]; });
-#else
+                // this lane half's vertex row (nearest: h = 0, twin: h = 1): channels = slots 0..28.  (The tensor's offset depends on h: it goes
+                // into the lane part of the address, 32 npad floats further for the h = 1 lanes.)
                 static_for<7>([&](auto qc) {
                     constexpr int t = 4 * decltype(qc)::value;
-                    *reinterpret_cast<float4*>(row + t) = make_float4(d_in_tex[t / 16][t % 16], d_in_tex[(t + 1) / 16][(t + 1) % 16],
-                                                                      d_in_tex[(t + 2) / 16][(t + 2) % 16], d_in_tex[(t + 3) / 16][(t + 3) % 16]);
+                    const u32x4 q = {__float_as_uint(d_in_tex[t / 16][t % 16]), __float_as_uint(d_in_tex[(t + 1) / 16][(t + 1) % 16]),
+                                     __float_as_uint(d_in_tex[(t + 2) / 16][(t + 2) % 16]), __float_as_uint(d_in_tex[(t + 3) / 16][(t + 3) % 16])};
+                    __builtin_amdgcn_raw_buffer_store_b128(q, S.ig, 4u * (S.col * 32u + (unsigned)t) + (unsigned)(IG_TEX + 32 * h) * S.row4, 0, 0);
                 });
-#endif
-                row[28] = d_in_tex[1][12];
-                float* xy = IGP(IG_TEX_XY, 8, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(d_in_tex[1][12]), S.ig, 4u * (S.col * 32u + 28u) + (unsigned)h * 32u * S.row4, (unsigned)IG_TEX * S.row4, 0);
                 // h = 0: slots 32..34 = tex 0..2 -> channels 0..2; h = 1: slots 29..33 = tex 3..7 -> channels 3..7.  Five stores from every lane, no
                 // branch (the h = 0 lanes repeat their last one)
                 static_for<5>([&](auto ic) {
                     constexpr int i = decltype(ic)::value, i0 = i < 2 ? i : 2;
                     const float v1 = d_in_tex[(29 + i) / 16][(29 + i) % 16], v0 = d_in_tex[2][i0];
-                    xy[h ? 3 + i : i0] = h ? v1 : v0;
+                    IG1(IG_TEX_XY, 8, h ? 3 + i : i0, h ? v1 : v0);
                 });
             }
         }
@@ -182,7 +210,7 @@ __global__ __launch_bounds__(BW_BLOCK, 1) void query_backward_kernel(const BwdPa
             f32x16 dy15[1];
             zero<1>(dy15);
             static_for<12>([&](auto rc) { constexpr int r = decltype(rc)::value; dy15[0][r] = d_in_tex[(35 + r) / 16][(35 + r) % 16]; });
-            store_dy<L_IBR>(regs(dy15), ycol_h, npad, h);
+            store_dy<L_IBR>(regs(dy15), S);
             bwd_pass<L_IBR, 0>(dpool, W, (unsigned)lane, regs(dy15));
         }
         // ================= density head: mlp_geo.layers2 (src/utils.py:709-719) =================
@@ -190,17 +218,17 @@ __global__ __launch_bounds__(BW_BLOCK, 1) void query_backward_kernel(const BwdPa
             f32x16 dy14[1];
             zero<1>(dy14);
             dy14[0][0] = d_out[0]; dy14[0][1] = d_out[1];
-            store_dy<L_HEAD2>(regs(dy14), ycol_h, npad, h);
+            store_dy<L_HEAD2>(regs(dy14), S);
             f32x16 dx14[2];
             bwd_pass<L_HEAD2, 0>(dx14, W, (unsigned)lane, regs(dy14));
             f32x16 dy13[2];
             static_for<32>([&](auto tc) { constexpr int t = decltype(tc)::value; dy13[t / 16][t % 16] = sp_g(X(LC(L_HEAD2), tc), dx14[t / 16][t % 16]); });
-            store_dy<L_HEAD1>(regs(dy13), ycol_h, npad, h);
+            store_dy<L_HEAD1>(regs(dy13), S);
             f32x16 dx13[2];
             bwd_pass<L_HEAD1, 0>(dx13, W, (unsigned)lane, regs(dy13));
             f32x16 dy12[2];
             static_for<32>([&](auto tc) { constexpr int t = decltype(tc)::value; dy12[t / 16][t % 16] = sp_g(X(LC(L_HEAD1), tc), dx13[t / 16][t % 16]); });
-            store_dy<L_HEAD0>(regs(dy12), ycol_h, npad, h);
+            store_dy<L_HEAD0>(regs(dy12), S);
             f32x16 dph[4];
             bwd_pass<L_HEAD0, 0>(dph, W, (unsigned)lane, regs(dy12));
 #pragma unroll
@@ -220,13 +248,13 @@ __global__ __launch_bounds__(BW_BLOCK, 1) void query_backward_kernel(const BwdPa
         f32x16 dg64[2];
         float dg8[4];
         {
-            store_dy<L_MLP3>(regs(dy11), ycol_h, npad, h);
+            store_dy<L_MLP3>(regs(dy11), S);
             f32x16 dx11[4];
             bwd_pass<L_MLP3, 0>(dx11, W, (unsigned)lane, regs(dy11));
             f32x16 dy10[4];
             zero<4>(dy10);
             static_for<60>([&](auto tc) { constexpr int t = decltype(tc)::value; dy10[t / 16][t % 16] = sp_g(X(LC(L_MLP3), tc), dx11[t / 16][t % 16]); });
-            store_dy<L_MLP2>(regs(dy10), ycol_h, npad, h);
+            store_dy<L_MLP2>(regs(dy10), S);
             f32x16 dx10a[4], dx10b[1];
             bwd_pass<L_MLP2, 0>(dx10a, W, (unsigned)lane, regs(dy10));
             bwd_pass<L_MLP2, 1>(dx10b, W, (unsigned)lane, regs(dy10));
@@ -234,12 +262,12 @@ __global__ __launch_bounds__(BW_BLOCK, 1) void query_backward_kernel(const BwdPa
             for (int r = 0; r < 4; ++r) dg8[r] = dx10b[0][r]; // slots 64..67: the 8-channel geometry feature, no activation in between
             f32x16 dy9[4];
             static_for<64>([&](auto tc) { constexpr int t = decltype(tc)::value; dy9[t / 16][t % 16] = sp_g(X(LC(L_MLP2), tc), dx10a[t / 16][t % 16]); });
-            store_dy<L_MLP1>(regs(dy9), ycol_h, npad, h);
+            store_dy<L_MLP1>(regs(dy9), S);
             f32x16 dx9[4];
             bwd_pass<L_MLP1, 0>(dx9, W, (unsigned)lane, regs(dy9));
             f32x16 dy8[4];
             static_for<64>([&](auto tc) { constexpr int t = decltype(tc)::value; dy8[t / 16][t % 16] = sp_g(X(LC(L_MLP1), tc), dx9[t / 16][t % 16]); });
-            store_dy<L_MLP0>(regs(dy8), ycol_h, npad, h);
+            store_dy<L_MLP0>(regs(dy8), S);
             f32x16 dx8[3]; // slot blocks 9..11 = k-pairs 144..191; the 64-channel geometry feature is k-pairs 147..178
             bwd_pass<L_MLP0, 0>(dx8, W, (unsigned)lane, regs(dy8));
             static_for<32>([&](auto uc) { constexpr int u = decltype(uc)::value, t = 147 + u - 144; dg64[u / 16][u % 16] = dx8[t / 16][t % 16]; });
@@ -250,13 +278,13 @@ __global__ __launch_bounds__(BW_BLOCK, 1) void query_backward_kernel(const BwdPa
             constexpr int HC = decltype(hc_c)::value, LA = decltype(la_c)::value, AG = decltype(aux_c)::value, IGB = decltype(ig_c)::value;
             constexpr int NBO = decltype(nbo_c)::value, NMID = decltype(nmid_c)::value; // blocks of the output / k-pairs of the hidden layer
             constexpr int NSB = kBNB[LA]; // slot blocks of the input
-            store_dy<LA + 3>(regs(dy_out), ycol_h, npad, h);
+            store_dy<LA + 3>(regs(dy_out), S);
             f32x16 dx3[NBO];
             bwd_pass<LA + 3, 0>(dx3, W, (unsigned)lane, regs(dy_out));
             f32x16 dy2[NBO];
             zero<NBO>(dy2);
             static_for<NMID>([&](auto tc) { constexpr int t = decltype(tc)::value; dy2[t / 16][t % 16] = relu_g(X(LC(LA + 3), tc), dx3[t / 16][t % 16]); });
-            store_dy<LA + 2>(regs(dy2), ycol_h, npad, h);
+            store_dy<LA + 2>(regs(dy2), S);
             f32x16 dxg[NSB]; // gradient of the gated input
             {
                 f32x16 pa[bwd_pass_blocks(LA + 2, 0)];
@@ -286,13 +314,13 @@ __global__ __launch_bounds__(BW_BLOCK, 1) void query_backward_kernel(const BwdPa
             dy1[0][0] = h ? 0.0f : s0 * a0 * (1.0f - a0);
             dy1[0][1] = h ? 0.0f : s1 * a1 * (1.0f - a1);
             dy1[0][2] = h ? 0.0f : s2 * a2 * (1.0f - a2);
-            store_dy<LA + 1>(regs(dy1), ycol_h, npad, h);
+            store_dy<LA + 1>(regs(dy1), S);
             f32x16 dx1[1];
             bwd_pass<LA + 1, 0>(dx1, W, (unsigned)lane, regs(dy1));
             f32x16 dy0[1];
             zero<1>(dy0);
             static_for<6>([&](auto tc) { constexpr int t = decltype(tc)::value; dy0[0][t] = relu_g(X(LC(LA + 1), tc), dx1[0][t]); });
-            store_dy<LA>(regs(dy0), ycol_h, npad, h);
+            store_dy<LA>(regs(dy0), S);
             {
                 f32x16 pa[bwd_pass_blocks(LA, 0)];
                 bwd_pass<LA, 0>(pa, W, (unsigned)lane, regs(dy0));
@@ -307,8 +335,8 @@ __global__ __launch_bounds__(BW_BLOCK, 1) void query_backward_kernel(const BwdPa
             }
             static_for<3 * HC / 4>([&](auto qc) { // group t / HC = pix | nearest | twin; channel HC h + t % HC: four consecutive channels per store
                 constexpr int t = 4 * decltype(qc)::value;
-                *reinterpret_cast<float4*>(IGP(IGB + 2 * HC * (t / HC), 2 * HC, HC * h + t % HC)) =
-                    make_float4(d_in[t / 16][t % 16], d_in[(t + 1) / 16][(t + 1) % 16], d_in[(t + 2) / 16][(t + 2) % 16], d_in[(t + 3) / 16][(t + 3) % 16]);
+                IG4(IGB + 2 * HC * (t / HC), 2 * HC, HC * h + t % HC, d_in[t / 16][t % 16], d_in[(t + 1) / 16][(t + 1) % 16], d_in[(t + 2) / 16][(t + 2) % 16],
+                    d_in[(t + 3) / 16][(t + 3) % 16]);
             });
         };
         {
@@ -336,6 +364,7 @@ extern "C" int vanerf_query_backward(const VanerfWeights* w, const float* d, con
         if (!w || !w->dev_bwd || w->mode != 0) throw_error("vanerf_query_backward: needs an fp32 weight handle (vanerf_weights_pack mode 0)");
         if (!d || !raw || !valid || !xs || !aux || !ys || !ig) throw_error("vanerf_query_backward: null argument");
         if (npad < n || npad % 32 != 0) throw_error("vanerf_query_backward: npad = %lld must be a multiple of 32 and >= n = %lld", (long long)npad, (long long)n);
+        if ((long long)X_ROWS * 4 * npad >= (long long)NO_COL) throw_error("vanerf_query_backward: a block of %lld samples spills more than 4 GB", (long long)npad);
         BwdParams P;
         P.wb = w->dev_bwd; P.wbytes = (unsigned)(w->n_floats_bwd * sizeof(float)); P.d = d; P.d2 = d2; P.noise = noise; P.noise2 = noise2; P.raw = raw; P.valid = valid; P.n = n; P.npad = npad;
         P.xs = xs; P.aux = aux; P.ys = ys; P.ig = ig;

@@ -370,18 +370,25 @@ template <int NB> struct RingSel<1, NB> { using type = RingB<NB>; };
 // spills starts -- null pointers in the inference kernel, where every store below folds away
 struct LLane {
     int lane;
-    float* xs;        // Xs + sample column + h * npad   (row r of the lane half: xs[(size_t)2 r * npad])
-    float* aux;       // the same into the auxiliary spill
-    long long npad;
+    // spill mode: buffer stores, offset = voff (this lane's column: 4 (col + h npad)) + a wave-uniform row offset (2 r x 4 npad) -- one s_mul and
+    // one store per value (global stores with 64-bit addresses took ~9 instructions each: 19.6 k instructions per group against 9.8 k without
+    // the spills).  A lane that must not spill holds voff = SPILL_OFF: beyond both buffers' sizes, so the hardware drops the store.
+    WRsrc xs, aux;       // Xs[X_ROWS][npad], Aux[AUX_ROWS][npad]
+    unsigned voff, row4; // row4 = 4 npad (bytes per row)
+    bool on;             // the kernel's SPILL parameter (a constant: the stores fold away in the other builds)
 };
+constexpr unsigned SPILL_OFF = 0xfffffff0u;
 template <int L, int t> __device__ __forceinline__ void spill_x(const LLane& la, float v)
 {
-    if (la.xs) la.xs[(size_t)(x_row_base(L) + 2 * t) * (size_t)la.npad] = v;
+    if (la.on) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), la.xs, la.voff, (unsigned)(x_row_base(L) + 2 * t) * la.row4, 0);
 }
 template <int K> __device__ __forceinline__ void spill_aux(const LLane& la, float v)
 {
-    if (la.aux) la.aux[(size_t)(2 * K) * (size_t)la.npad] = v;
+    if (la.on) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), la.aux, la.voff, (unsigned)(2 * K) * la.row4, 0);
 }
+#ifndef VANERF_WAVES_PER_SIMD_SPILL
+#define VANERF_WAVES_PER_SIMD_SPILL 1
+#endif
 template <int MODE> struct LaneSel { using type = LLane; };
 template <> struct LaneSel<1> { using type = LAddr; };
 __device__ __forceinline__ unsigned lane_of(const LLane& la) { return (unsigned)la.lane; }
@@ -593,7 +600,7 @@ __device__ __forceinline__ void geo_scale(WRsrc W, int lane, const typename Lane
 }
 
 template <int MODE, bool SPILL = false>
-__global__ __launch_bounds__(64 * WPB<MODE>, MODE == 1 ? VANERF_WAVES_PER_SIMD_B : (SPILL ? 1 : VANERF_WAVES_PER_SIMD)) void query_kernel(const QueryParams P)
+__global__ __launch_bounds__(64 * WPB<MODE>, MODE == 1 ? VANERF_WAVES_PER_SIMD_B : (SPILL ? VANERF_WAVES_PER_SIMD_SPILL : VANERF_WAVES_PER_SIMD)) void query_kernel(const QueryParams P)
 {
     static_assert(!SPILL || MODE == 0, "the training spill runs on the fp32 kernel");
     constexpr int WAVES_PER_BLOCK = WPB<MODE>, BLOCK = 64 * WAVES_PER_BLOCK;
@@ -609,6 +616,11 @@ __global__ __launch_bounds__(64 * WPB<MODE>, MODE == 1 ? VANERF_WAVES_PER_SIMD_B
     const unsigned wbytes_eff = P.wbytes;
 #endif
     const WRsrc W = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.w), 0, wbytes_eff, 0x00020000); // kernarg-derived: wave-uniform
+    [[maybe_unused]] WRsrc xs_rs = W, aux_rs = W; // spill mode: the two spills as buffers of their exact sizes (the host checks they stay below 4 GB)
+    if constexpr (SPILL) {
+        xs_rs = __builtin_amdgcn_make_buffer_rsrc(P.xs, 0, (unsigned)(X_ROWS * 4ll * P.npad), 0x00020000);
+        aux_rs = __builtin_amdgcn_make_buffer_rsrc(P.aux, 0, (unsigned)(AUX_ROWS * 4ll * P.npad), 0x00020000);
+    }
 
 #ifdef VANERF_STAMPS
     unsigned long long phase_cycles[N_PHASES] = {};
@@ -691,10 +703,16 @@ __global__ __launch_bounds__(64 * WPB<MODE>, MODE == 1 ? VANERF_WAVES_PER_SIMD_B
         [[maybe_unused]] unsigned kp_lds = 0;
         if constexpr (MODE == 1) { la = make_laddr(lane, wv_u); kp_lds = LDS_KPT + ((la.w[0] >> 9) & 1u) * (PE_KPT_PER_HALF * 16u); }
         else {
-            la.lane = lane; la.xs = nullptr; la.aux = nullptr; la.npad = 0;
-            if (SPILL && g < ngroups) { // column = the slot's own place g * 32 + j (also for lanes beyond n: their output gradient is zero)
-                const size_t col = (size_t)g * 32 + (size_t)j + (size_t)h * (size_t)P.npad;
-                la.xs = P.xs + col; la.aux = P.aux + col; la.npad = P.npad;
+            la.lane = lane; la.voff = SPILL_OFF; la.row4 = 0; la.on = SPILL;
+            if constexpr (SPILL) {
+                la.xs = xs_rs; la.aux = aux_rs;
+                // the row stride, opaque per round: hoisted out of the work loop the ~1 100 row offsets are parked in registers.  (Set on every
+                // path: a value that depends on the group index is divergent to the compiler, and a divergent store offset is a waterfall loop.)
+                unsigned r4 = (unsigned)P.npad * 4u;
+                asm volatile("" : "+s"(r4));
+                la.row4 = r4;
+                // column = the slot's own place g * 32 + j (also for lanes beyond n: their output gradient is zero); no column beyond the last group
+                if (g < ngroups) la.voff = 4u * ((unsigned)g * 32u + (unsigned)j) + (unsigned)h * r4;
             }
         }
         const long long s_raw = g * 32 + j;
@@ -1109,6 +1127,9 @@ extern "C" int vanerf_query_forward_spill(const VanerfWeights* w, const VanerfFr
         if (!frame || !pts || !query_sdf || !query_vis || !knn_idx || !out_raw || !xs || !aux) throw_error("vanerf_query_forward_spill: null argument");
         if (!queue_word || (reinterpret_cast<uintptr_t>(queue_word) & 7u)) throw_error("vanerf_query_forward_spill: queue_word must be 8 bytes of device memory, 8-byte aligned");
         if (npad < n || npad % 32 != 0) throw_error("vanerf_query_forward_spill: npad = %lld must be a multiple of 32 and >= n = %lld", (long long)npad, (long long)n);
+        if ((long long)X_ROWS * 4 * npad >= (long long)SPILL_OFF)
+            throw_error("vanerf_query_forward_spill: a block of %lld samples spills more than 4 GB (the kernels address the spills with 32-bit offsets): at most %lld",
+                        (long long)npad, (long long)SPILL_OFF / (4 * X_ROWS) / 32 * 32);
         const VanerfFrame& f = *frame;
         if (!f.geo0 || !f.geo1 || !f.tex || !f.img || !f.mask || !f.verts || !f.vfeat0 || !f.vfeat1 || !f.vfeat_tex || !f.vert_vis || !f.kpt_cam)
             throw_error("vanerf_query_forward_spill: frame has a null pointer");
