@@ -388,3 +388,35 @@ def test_backward_chain_is_a_pure_function_of_the_sample():
         assert torch.equal(small.ys[:, :part], ys_all[:, sl]), b0
         for k, v in ig.items():
             assert torch.equal(v, ig_all[k][sl]), (k, b0)
+
+
+@pytest.mark.parametrize("npad", [65536, 2048, 96])
+def test_weight_products_kernel_against_matrix_products(npad):
+    """vanerf_weight_products (every layer's dW' += Ys Xs^T in one launch) against fp64 matrix products of the same spills, and against the sliced
+    torch.baddbmm path it replaced: random spills, accumulation into a non-zero accumulator, a block too short for the slicing (one slice), and
+    two launches in a row give the same bits (one wave per accumulator, fixed order)."""
+    from vanerf_amd import hip_backward as HB
+    ws = HB.Workspace(npad, "cuda")
+    g = torch.Generator(device="cuda").manual_seed(npad)
+    ws.xs.copy_(torch.randn(ws.xs.shape, device="cuda", generator=g))
+    ws.ys.copy_(torch.randn(ws.ys.shape, device="cuda", generator=g))
+    base = torch.randn(ws.dw.shape, device="cuda", generator=g)
+    ws.dw.copy_(base)
+    HB._weight_products_on(ws, ws.xs, ws.ys, npad)
+    got = ws.dw.clone()
+    ws.dw.copy_(base)
+    HB._weight_products_on(ws, ws.xs, ws.ys, npad)
+    assert torch.equal(ws.dw, got)
+    ws.dw.copy_(base)
+    HB._weight_products_on(ws, ws.xs, ws.ys, npad, use_torch=True)
+    via_torch = ws.dw.clone()
+    L = HB.layout()
+    ws.dw.copy_(got)
+    for li, lay in enumerate(L["layers"]):
+        want = ws.ys[lay["y_row"]:lay["y_row"] + lay["n_out"]].double() @ ws.xs[lay["x_row"]:lay["x_row"] + lay["n_slots"]].double().t()
+        ws.dw.copy_(base); b0 = ws.dw_l[li].double().sum(0)
+        ws.dw.copy_(got); have = ws.dw_l[li].double().sum(0) - b0
+        ws.dw.copy_(via_torch); ref = ws.dw_l[li].double().sum(0) - b0
+        scale = want.abs().max().item()
+        assert (have - want).abs().max().item() <= 2e-5 * scale + 1e-4, (li, (have - want).abs().max().item(), scale)
+        assert (have - want).abs().max().item() <= 2.0 * (ref - want).abs().max().item() + 1e-4 * scale, li  # no worse than the library products

@@ -95,6 +95,8 @@ _SIGS = {
     "vanerf_query_samples": (c_int, [c_void_p, POINTER(VanerfFrame), _FP, _FP, _FP, _FP, _FP, _FP, c_int, c_int64, _FP, _FP, _FP, c_void_p]),
     "vanerf_query_forward_spill": (c_int, [c_void_p, POINTER(VanerfFrame), _FP, _FP, _FP, _FP, c_int64, c_int64, _FP, _FP, _FP, _FP, _FP, c_void_p]),
     "vanerf_query_backward": (c_int, [c_void_p, _FP, _FP, _FP, _FP, _FP, _FP, c_int64, c_int64, _FP, _FP, _FP, _FP, c_void_p]),
+    "vanerf_weight_products": (c_int, [_FP, _FP, c_int64, c_int, c_int, _FP, c_void_p]),
+    "vanerf_weight_products_size": (c_int, [POINTER(c_int64)]),
     "vanerf_spill_rows": (c_int, [POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
     "vanerf_layer_slots": (c_int, [c_int, _FP, c_int]),
     "vanerf_layer_rows": (c_int, [c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int)]),

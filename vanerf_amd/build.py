@@ -7,7 +7,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib", "libvanerf_hip.so")
-SOURCES = ["api.cpp", "weights_pack.cpp", "pass.cpp", "query_kernel.hip", "render_kernels.hip", "mesh_kernels.hip", "train_kernels.hip", "query_backward.hip", "weights_update.hip"]
+SOURCES = ["api.cpp", "weights_pack.cpp", "pass.cpp", "query_kernel.hip", "render_kernels.hip", "mesh_kernels.hip", "train_kernels.hip", "query_backward.hip", "weights_update.hip", "weight_products.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-Wall", "-Wextra", "-Wno-unused-parameter"]
 # per-file flags.  query_kernel.hip: MFMA results are allocated in VGPRs (the chained layers read every accumulator element once with VALU

@@ -1,0 +1,213 @@
+// weight_products.hip -- the weight gradients of the fused backward pass: dW'_l[out][slot] += Ys_l Xs_l^T over a block's samples, all twenty layers
+// in ONE launch (hip_backward.py did this with one sliced torch.baddbmm per layer: 160 launches and 3.7 ms per training step, the library GEMMs
+// at ~1.7 TB/s on a 128 x 360 output over 65 536 samples).
+// * Shape of the work: outputs are tiny (965 x ~2 074 values in all), the reduction dimension is the block's samples.  The samples are cut into
+//   `slices`; a wave owns (a group of up to 2 x 4 tiles of 32 x 32 outputs of one layer, one slice) and accumulates in place into
+//   dw[layer][slice][out][slot] -- exactly one wave per accumulator per launch: no atomics, sums in a fixed order, reproducible run to run.
+// * Operands: v_mfma_f32_32x32x2_f32, A = Ys rows (lane = out row, k half), B = Xs rows (lane = slot, k half); both spills are channel-major with the
+//   samples contiguous, so a lane streams ITS row 16 bytes at a time: 64 bytes at a time.
+// * Rows beyond a layer's own (partial tiles) are loaded from a clamped row and zeroed; tiles beyond a task's count are skipped wave-uniformly.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <mutex>
+#include <vector>
+
+#include "common.h"
+#include "mfma_chain.h"
+
+using namespace vanerf;
+using namespace vanerf_chain;
+
+namespace {
+
+constexpr int MG = 2, NG = 4; // tiles of a wave's group: 64 output rows x 128 slots
+struct WpTask {
+    int y_row, x_row;   // first row of the group in Ys / Xs
+    int n_out, n_slot;  // rows of the layer left from there (the group uses min(., 32 MG) / min(., 32 NG))
+    int ld;             // slots of the layer (row length of its accumulator)
+    unsigned dw_off;    // offset of the layer's accumulator [slices][n_out_layer][ld] in floats ...
+    unsigned dw_layer;  // ... and its size per slice
+    int out0, slot0;    // the group's first output row / slot inside the layer
+};
+
+__global__ __launch_bounds__(256, 1) void weight_products_kernel(const WpTask* __restrict__ tasks, int ntasks, const float* __restrict__ xs,
+                                                                 const float* __restrict__ ys, long long npad, int slices, float* __restrict__ dw)
+{
+    const int lane = threadIdx.x & 63, i = lane & 31, kh = lane >> 5;
+    const int tg = blockIdx.x / slices, slice = blockIdx.x % slices;
+    const int ti = __builtin_amdgcn_readfirstlane(tg * 4 + (int)(threadIdx.x >> 6));
+    if (ti >= ntasks) return;
+    const WpTask T = tasks[ti];
+    const int mt_n = (min(T.n_out, 32 * MG) + 31) / 32, nt_n = (min(T.n_slot, 32 * NG) + 31) / 32; // wave-uniform
+    const long long per = npad / slices, s0 = (long long)slice * per;
+    // this lane's rows (clamped into the layer) and whether they exist
+    const float* ap[MG];
+    const float* bp[NG];
+    bool av[MG], bv[NG];
+#pragma unroll
+    for (int m = 0; m < MG; ++m) {
+        const int r = 32 * m + i;
+        av[m] = r < T.n_out;
+        ap[m] = ys + (size_t)(T.y_row + (av[m] ? r : 0)) * (size_t)npad + s0 + 16 * kh;
+    }
+#pragma unroll
+    for (int n = 0; n < NG; ++n) {
+        const int r = 32 * n + i;
+        bv[n] = r < T.n_slot;
+        bp[n] = xs + (size_t)(T.x_row + (bv[n] ? r : 0)) * (size_t)npad + s0 + 16 * kh;
+    }
+    f32x16 acc[MG][NG];
+#pragma unroll
+    for (int m = 0; m < MG; ++m)
+#pragma unroll
+        for (int n = 0; n < NG; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
+    // One batch = 32 samples: a lane takes 64 contiguous bytes of its row (samples s + 16 kh .. + 15, four 16-byte loads), so the two lanes of a row
+    // consume a whole 128-byte line at once (16 bytes per visit fetched every line four times: 0.80 ms per block).  The next batch's 24 loads are in
+    // flight under this batch's 128 products (the kernel takes the whole register file: one wave per SIMD, 8 192 MFMA cycles per batch to hide them).
+    struct Batch { float4 a[MG][4], b[NG][4]; };
+    const float4 zero4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    auto load = [&](Batch& B, long long s) {
+#pragma unroll
+        for (int m = 0; m < MG; ++m)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) B.a[m][q] = (m < mt_n) ? reinterpret_cast<const float4*>(ap[m] + s)[q] : zero4;
+#pragma unroll
+        for (int n = 0; n < NG; ++n)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) B.b[n][q] = (n < nt_n) ? reinterpret_cast<const float4*>(bp[n] + s)[q] : zero4;
+    };
+    auto products = [&](Batch& B) {
+#pragma unroll
+        for (int m = 0; m < MG; ++m) if (!av[m]) { B.a[m][0] = zero4; B.a[m][1] = zero4; B.a[m][2] = zero4; B.a[m][3] = zero4; }
+#pragma unroll
+        for (int n = 0; n < NG; ++n) if (!bv[n]) { B.b[n][0] = zero4; B.b[n][1] = zero4; B.b[n][2] = zero4; B.b[n][3] = zero4; }
+#pragma unroll
+        for (int m = 0; m < MG; ++m) {
+            if (m >= mt_n) break;
+#pragma unroll
+            for (int n = 0; n < NG; ++n) {
+                if (n >= nt_n) break;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(B.a[m][q].x, B.b[n][q].x, acc[m][n], 0, 0, 0);
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(B.a[m][q].y, B.b[n][q].y, acc[m][n], 0, 0, 0);
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(B.a[m][q].z, B.b[n][q].z, acc[m][n], 0, 0, 0);
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(B.a[m][q].w, B.b[n][q].w, acc[m][n], 0, 0, 0);
+                }
+            }
+        }
+    };
+    Batch B0, B1;
+    load(B0, 0);
+    for (long long s = 0; s < per; s += 64) {
+        if (s + 32 < per) load(B1, s + 32);
+        products(B0);
+        if (s + 32 >= per) break;
+        if (s + 64 < per) load(B0, s + 64);
+        products(B1);
+    }
+    // accumulate: register r of lane l holds row (r & 3) + 8 (r >> 2) + 4 (l >> 5), column l & 31 of the tile
+    float* out = dw + T.dw_off + (size_t)slice * T.dw_layer;
+#pragma unroll
+    for (int m = 0; m < MG; ++m) {
+        if (m >= mt_n) break;
+#pragma unroll
+        for (int n = 0; n < NG; ++n) {
+            if (n >= nt_n) break;
+            const int c = 32 * n + i;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = 32 * m + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                if (row < T.n_out && c < T.n_slot) {
+                    float* q = out + (size_t)(T.out0 + row) * T.ld + T.slot0 + c;
+                    *q += acc[m][n][r];
+                }
+            }
+        }
+    }
+}
+
+struct TaskTable {
+    std::vector<WpTask> host;
+    unsigned total = 0; // floats per slice of the whole accumulator
+};
+const TaskTable& task_table()
+{
+    static const TaskTable t = [] {
+        TaskTable tt;
+        unsigned off = 0;
+        struct Lay { unsigned off; int n_out, n_slot; };
+        std::vector<Lay> lays;
+        for (int l = 0; l < NUM_LAYERS; ++l) {
+            lays.push_back({off, kNOUT[l], 2 * kT[l]});
+            off += (unsigned)(kNOUT[l] * 2 * kT[l]);
+        }
+        tt.total = off;
+        for (int l = 0; l < NUM_LAYERS; ++l)
+            for (int o = 0; o < kNOUT[l]; o += 32 * MG)
+                for (int c = 0; c < 2 * kT[l]; c += 32 * NG) {
+                    WpTask t{};
+                    t.y_row = y_row_base(l) + o; t.x_row = x_row_base(l) + c;
+                    t.n_out = kNOUT[l] - o; t.n_slot = 2 * kT[l] - c; t.ld = 2 * kT[l];
+                    t.dw_off = 0; t.dw_layer = (unsigned)(kNOUT[l] * 2 * kT[l]); t.out0 = o; t.slot0 = c;
+                    t.x_row = x_row_base(l) + c;
+                    t.dw_off = lays[l].off; // x slices: filled in per launch (the layer's accumulator starts at slices x this)
+                    tt.host.push_back(t);
+                }
+        // heavy groups first: the four waves of a block then carry similar work, and the launch ends on the light ones
+        auto weight = [](const WpTask& t) { return ((std::min(t.n_out, 32 * MG) + 31) / 32) * ((std::min(t.n_slot, 32 * NG) + 31) / 32); };
+        std::stable_sort(tt.host.begin(), tt.host.end(), [&](const WpTask& a, const WpTask& b) { return weight(a) > weight(b); });
+        return tt;
+    }();
+    return t;
+}
+
+// per (device, slices): the table with the accumulator offsets of that slicing
+struct DevTable { WpTask* dev = nullptr; int n = 0; };
+const DevTable& device_table(int device, int slices)
+{
+    static std::mutex mu;
+    static std::vector<std::pair<std::pair<int, int>, DevTable>> cache;
+    std::lock_guard<std::mutex> lock(mu);
+    for (auto& e : cache)
+        if (e.first == std::make_pair(device, slices)) return e.second;
+    std::vector<WpTask> h = task_table().host;
+    for (WpTask& t : h) t.dw_off *= (unsigned)slices;
+    DevTable d;
+    d.n = (int)h.size();
+    HIP_CHECK(hipMalloc(&d.dev, h.size() * sizeof(WpTask)));
+    HIP_CHECK(hipMemcpy(d.dev, h.data(), h.size() * sizeof(WpTask), hipMemcpyHostToDevice));
+    cache.emplace_back(std::make_pair(device, slices), d);
+    return cache.back().second;
+}
+
+} // namespace
+
+// dw: layout_slices x (sum over the layers of n_out x n_slots) floats, layer l at layout_slices x (its offset), [layout_slices][n_out][n_slots] -- accumulated into.
+// slices <= layout_slices: a block too short to be cut `layout_slices` times accumulates into the first `slices` parts of the same accumulator.
+extern "C" int vanerf_weight_products(const float* xs, const float* ys, int64_t npad, int slices, int layout_slices, float* dw, void* stream)
+{
+    return guarded([&] {
+        if (!xs || !ys || !dw) throw_error("vanerf_weight_products: null argument");
+        if (slices <= 0 || slices > layout_slices || npad <= 0 || npad % ((int64_t)slices * 32) != 0)
+            throw_error("vanerf_weight_products: npad = %lld must be a multiple of 32 x slices = %d, slices <= layout_slices = %d", (long long)npad, 32 * slices, layout_slices);
+        int device = 0;
+        HIP_CHECK(hipGetDevice(&device));
+        const DevTable& t = device_table(device, layout_slices);
+        const unsigned blocks = (unsigned)((t.n + 3) / 4) * (unsigned)slices;
+        hipLaunchKernelGGL(weight_products_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, t.dev, t.n, xs, ys, (long long)npad, slices, dw);
+        HIP_CHECK(hipGetLastError());
+    });
+}
+
+// floats per slice of the accumulator (= the sum over the layers of n_out x n_slots)
+extern "C" int vanerf_weight_products_size(int64_t* floats_per_slice)
+{
+    return guarded([&] {
+        if (!floats_per_slice) throw_error("vanerf_weight_products_size: null argument");
+        *floats_per_slice = (int64_t)task_table().total;
+    });
+}

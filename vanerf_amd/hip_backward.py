@@ -114,12 +114,16 @@ def run_block(ws, w0, fdat, pts, q_sdf, q_vis, knn, d, noise=None, d2=None, nois
     return input_gradients(ig, n, npad), n
 
 
-def _weight_products_on(ws, xs, ys, npad):
+def _weight_products_on(ws, xs, ys, npad, use_torch=False):
     """dW'_l += Ys_l Xs_l^T for every layer.  The reduction over the block's samples is cut into slices -- the output is tiny and an unsliced
-    product runs on a handful of CUs (1.95 ms against 0.52 ms per block, tools/bench_dw_products.py) -- and every slice accumulates in place
-    (ONE baddbmm per layer and block); the slices are summed once per step."""
+    product runs on a handful of CUs -- and every slice accumulates in place; the slices are summed once per step.  One launch of
+    vanerf_weight_products for all twenty layers (csrc/weight_products.hip); use_torch: one sliced torch.baddbmm per layer, the path it replaced
+    (160 launches and 3.7 ms per step; kept as the checker, tools/bench_dw_products.py)."""
     L = layout()
-    S = ws.slices if npad % ws.slices == 0 else 1
+    S = ws.slices if npad % (32 * ws.slices) == 0 else 1
+    if not use_torch:
+        check(lib.vanerf_weight_products(_ptr(xs), _ptr(ys), npad, S, ws.slices, _ptr(ws.dw), R._stream()))
+        return
     per = npad // S
     for lay, acc in zip(L["layers"], ws.dw_l):
         g = ys[lay["y_row"]:lay["y_row"] + lay["n_out"]]
