@@ -246,6 +246,13 @@ int vanerf_composite_merged(const float* rgba_c, const float* mesh_sdf_c, int Sc
 int vanerf_composite_handle(const VanerfWeights* w, const float* rgba, const float* z, const float* mesh_sdf, int Sa, const float* rgba_n,
                             const float* mesh_sdf_n, int Sn, const int32_t* src, int R, float* color, float* depth, float* alpha, float* sdf,
                             float* contrib, void* stream);
+/* Training: the backward of either composite (reference: autograd through rgba2out / sdf_activation, src/model.py:1464-1494, 879-882), tables and src as
+ * vanerf_composite_handle.  g_color [R][3], g_depth, g_alpha, g_sdf [R]: gradients with respect to the composite's outputs (any may be NULL = 0);
+ * d_rgba [R][Sa][5] (and d_rgba_n [R][Sn][5]): gradient with respect to every table entry (each is written once), d_beta [R] or NULL: the rays' shares
+ * of the gradient with respect to the (clamped) sigmoid_beta.  At most 256 samples per ray.                                                            */
+int vanerf_composite_backward(const VanerfWeights* w, const float* rgba, const float* z, const float* mesh_sdf, int Sa, const float* rgba_n,
+                              const float* mesh_sdf_n, int Sn, const int32_t* src, int R, const float* g_color, const float* g_depth,
+                              const float* g_alpha, const float* g_sdf, float* d_rgba, float* d_rgba_n, float* d_beta, void* stream);
 
 /* a17  importance_sample + sort-merge (src/model.py:1424-1462, 1301-1307):
  *     contrib[R][Sc], z[R][Sc], u[R][Sf] (random draws) or NULL with t_lin[Sf] = th.linspace(0, 1, Sf) (uniform=True) ->

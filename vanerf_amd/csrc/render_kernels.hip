@@ -485,6 +485,142 @@ static void launch_composite(const float* rgba, const float* z, const float* msd
     HIP_CHECK(hipGetLastError());
 }
 
+// Backward of the composite (training; the reference differentiates rgba2out with autograd: src/model.py:1464-1494, sdf_activation 879-882).  One wave per
+// ray, the forward quantities recomputed as composite_wave_kernel computes them, then with gw_i = dL/dw_i
+//   dL/dsigma_i = dist_i (gw_i T_{i+1} - sum_{k>i} gw_k w_k)        (T_{i+1} = T_i (1 - c_i); no division by (1 - c_i): exact zeros stay zeros, which is what
+//                                                                   torch.cumprod's backward branches -- and blocks the host -- for)
+//   dL/dx_i = -dL/dsigma_i s(1 - s) / beta^2,  x = rgba0 + mesh_sdf, s = sigmoid(-x / beta);   dL/dbeta = sum_i dL/dsigma_i (s(1 - s) x / beta^3 - s / beta^2)
+//   dL/drgb_i = g_color w_i,   dL/drgba1_i = g_sdf w_i / (acc + 1e-8)
+// with gw_i = g_color . rgb_i + g_alpha + g_depth (z_i - depth) / (acc + 1e-8) + g_sdf (rgba1_i - sdf) / (acc + 1e-8).  The gradients go back to the table a
+// sample came from (src as in the forward kernel: every table entry appears once in the merged order, so plain stores).  d_beta[r]: the ray's share.
+template <int SPL>
+__global__ __launch_bounds__(256) void composite_backward_kernel(const float* __restrict__ rgba, const float* __restrict__ z, const float* __restrict__ msdf,
+                                                                 const float* __restrict__ rgba_b, const float* __restrict__ msdf_b,
+                                                                 const int32_t* __restrict__ src, int Sa, int Sb, int R, int S, const float* __restrict__ beta_dev,
+                                                                 const float* __restrict__ g_color, const float* __restrict__ g_depth,
+                                                                 const float* __restrict__ g_alpha, const float* __restrict__ g_sdf,
+                                                                 float* __restrict__ d_a, float* __restrict__ d_b, float* __restrict__ d_beta)
+{
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= R) return; // whole wave
+    const float beta = *beta_dev;
+    const float* qa = rgba + (size_t)r * Sa * 5;
+    const float* ma = msdf + (size_t)r * Sa;
+    const float* qb = rgba_b ? rgba_b + (size_t)r * Sb * 5 : nullptr;
+    const float* mb = msdf_b ? msdf_b + (size_t)r * Sb : nullptr;
+    const int32_t* sr = src ? src + (size_t)r * S : nullptr;
+    const float* zr = z + (size_t)r * S;
+    float c[SPL], zi[SPL], dist[SPL], x[SPL], sg[SPL], q1[SPL], q2[SPL], q3[SPL], q4[SPL];
+    int from[SPL]; // where the sample's gradient goes: >= 0 entry of table a, < 0 entry ~from of table b
+    float lane_keep = 1.0f;
+#pragma unroll
+    for (int k = 0; k < SPL; ++k) {
+        const int i = lane * SPL + k;
+        c[k] = 0.0f; zi[k] = 0.0f; dist[k] = 0.0f; x[k] = 0.0f; sg[k] = 0.0f; q1[k] = q2[k] = q3[k] = q4[k] = 0.0f; from[k] = 0;
+        if (i < S) {
+            zi[k] = zr[i];
+            dist[k] = i + 1 < S ? zr[i + 1] - zi[k] : 1e10f;
+            const float* q;
+            float m;
+            if (sr) {
+                const int kk = sr[i];
+                from[k] = kk;
+                if (kk >= 0) { q = qa + 5 * kk; m = ma[kk]; } else { q = qb + 5 * (~kk); m = mb[~kk]; }
+            } else {
+                from[k] = i;
+                q = qa + 5 * i; m = ma[i];
+            }
+            x[k] = q[0] + m;
+            sg[k] = 1.0f / (1.0f + expf(-(-x[k] / beta))); // sigmoid(-x / beta)
+            c[k] = 1.0f - expf(-(sg[k] / beta) * dist[k]);
+            q1[k] = q[1]; q2[k] = q[2]; q3[k] = q[3]; q4[k] = q[4];
+        }
+        lane_keep *= 1.0f - c[k];
+    }
+    float incl = lane_keep;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const float v = __shfl_up(incl, d);
+        if (lane >= d) incl *= v;
+    }
+    float T0 = __shfl_up(incl, 1);
+    if (lane == 0) T0 = 1.0f;
+    float w[SPL], Tn[SPL]; // w_i and T_{i+1}
+    float ca = 0.0f, cs = 0.0f, cd = 0.0f;
+    {
+        float T = T0;
+#pragma unroll
+        for (int k = 0; k < SPL; ++k) {
+            w[k] = c[k] * T;
+            T = T * (1.0f - c[k]);
+            Tn[k] = T;
+            ca += w[k]; cs += q1[k] * w[k]; cd += zi[k] * w[k];
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { ca += __shfl_xor(ca, d); cs += __shfl_xor(cs, d); cd += __shfl_xor(cd, d); }
+    const float inv = 1.0f / (ca + 1e-8f), depth = cd * inv, sdfo = cs * inv;
+    const float gc0 = g_color ? g_color[3 * r] : 0.0f, gc1 = g_color ? g_color[3 * r + 1] : 0.0f, gc2 = g_color ? g_color[3 * r + 2] : 0.0f;
+    const float gd = g_depth ? g_depth[r] : 0.0f, ga = g_alpha ? g_alpha[r] : 0.0f, gs = g_sdf ? g_sdf[r] : 0.0f;
+    float gw[SPL], lane_sum = 0.0f;
+#pragma unroll
+    for (int k = 0; k < SPL; ++k) {
+        gw[k] = (gc0 * q2[k] + gc1 * q3[k] + gc2 * q4[k]) + ga + gd * (zi[k] - depth) * inv + gs * (q1[k] - sdfo) * inv;
+        lane_sum += gw[k] * w[k];
+    }
+    // exclusive suffix sum of lane_sum over the lanes (what the lanes behind this one contribute)
+    float sincl = lane_sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const float v = __shfl_down(sincl, d);
+        if (lane + d < 64) sincl += v;
+    }
+    float Sx = __shfl_down(sincl, 1);
+    if (lane == 63) Sx = 0.0f;
+    float dbeta = 0.0f;
+#pragma unroll
+    for (int k = SPL - 1; k >= 0; --k) {
+        const int i = lane * SPL + k;
+        if (i < S) {
+            const float dsig = dist[k] * (gw[k] * Tn[k] - Sx); // (last sample: dist = 1e10, T_{S} and the suffix are what they are -- torch's own product)
+            const float ss = sg[k] * (1.0f - sg[k]);
+            const float b2 = beta * beta;
+            float* o = from[k] >= 0 ? d_a + ((size_t)r * Sa + from[k]) * 5 : d_b + ((size_t)r * Sb + (~from[k])) * 5;
+            o[0] = -dsig * ss / b2;
+            o[1] = gs * w[k] * inv;
+            o[2] = gc0 * w[k]; o[3] = gc1 * w[k]; o[4] = gc2 * w[k];
+            dbeta += dsig * (ss * x[k] / (b2 * beta) - sg[k] / b2);
+        }
+        Sx += gw[k] * w[k];
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) dbeta += __shfl_xor(dbeta, d);
+    if (lane == 0 && d_beta) d_beta[r] = dbeta;
+}
+
+extern "C" int vanerf_composite_backward(const VanerfWeights* w, const float* rgba, const float* z, const float* mesh_sdf, int Sa, const float* rgba_n,
+                                         const float* mesh_sdf_n, int Sn, const int32_t* src, int R, const float* g_color, const float* g_depth,
+                                         const float* g_alpha, const float* g_sdf, float* d_rgba, float* d_rgba_n, float* d_beta, void* stream)
+{
+    return guarded([&] {
+        if (!w || !w->dev_beta || !rgba || !z || !mesh_sdf || !d_rgba) throw_error("vanerf_composite_backward: null argument");
+        if (rgba_n && (!mesh_sdf_n || !src || Sn <= 0 || !d_rgba_n)) throw_error("vanerf_composite_backward: the second table needs mesh_sdf_n, src, d_rgba_n and Sn > 0");
+        const int Sb = rgba_n ? Sn : 0, S = Sa + Sb;
+        if (R <= 0 || Sa <= 0 || S > 256) throw_error("vanerf_composite_backward: R=%d, %d samples per ray (at most 256)", R, S);
+        const dim3 wg((R + 3) / 4), wb(256);
+#define VANERF_CB(SPL)                                                                                                                              \
+    hipLaunchKernelGGL(composite_backward_kernel<SPL>, wg, wb, 0, (hipStream_t)stream, rgba, z, mesh_sdf, rgba_n, rgba_n ? mesh_sdf_n : nullptr,          \
+                       rgba_n ? src : nullptr, Sa, Sb, R, S, w->dev_beta, g_color, g_depth, g_alpha, g_sdf, d_rgba, d_rgba_n, d_beta)
+        if (S <= 64) VANERF_CB(1);
+        else if (S <= 128) VANERF_CB(2);
+        else if (S <= 192) VANERF_CB(3);
+        else VANERF_CB(4);
+#undef VANERF_CB
+        HIP_CHECK(hipGetLastError());
+    });
+}
+
 // pass.cpp's composites: sigmoid_beta from the weight handle's device copy (see vanerf_weights_update); rgba_b == null: one table of S = Sa samples
 void vanerf::composite_with_handle(const VanerfWeights* w, const float* rgba, const float* z, const float* msdf, const float* rgba_b, const float* msdf_b,
                                    const int32_t* src, int Sa, int Sb, int R, float* color, float* depth, float* alpha, float* sdf, float* contrib,

@@ -446,6 +446,28 @@ def composite(rgba, z, mesh_sdf, beta, want_contrib=True):
     return color, depth, alpha, contrib, sdf
 
 
+def composite_backward(weights, rgba, z, mesh_sdf, g_color=None, g_depth=None, g_alpha=None, g_sdf=None, rgba_n=None, sdf_n=None, src=None):
+    """Backward of composite() / composite_merged() (vanerf_composite_backward): gradients with respect to the composite's outputs in, gradient with
+    respect to every table entry out -> (d_rgba (R,Sa,5), d_rgba_n (R,Sn,5) or None, d_beta (R,): the rays' shares of d / d clamp(sigmoid_beta)).
+    sigmoid_beta is the weight handle's device copy; at most 256 samples per ray."""
+    R, S = z.shape
+    Sa = mesh_sdf.shape[1]
+    Sn = 0 if rgba_n is None else sdf_n.shape[1]
+    assert Sa + Sn == S and (src is None) == (rgba_n is None)
+    dev = z.device
+    f32 = torch.float32
+    d_a = torch.empty(R, Sa, 5, dtype=f32, device=dev)
+    d_n = torch.empty(R, Sn, 5, dtype=f32, device=dev) if Sn else None
+    d_beta = torch.empty(R, dtype=f32, device=dev)
+    c = lambda t: None if t is None else t.to(f32).contiguous()
+    g_color, g_depth, g_alpha, g_sdf = c(g_color), c(g_depth), c(g_alpha), c(g_sdf)
+    rgba, z, mesh_sdf, rgba_n, sdf_n = c(rgba), c(z), c(mesh_sdf), c(rgba_n), c(sdf_n)
+    src = None if src is None else src.to(torch.int32).contiguous()
+    check(lib.vanerf_composite_backward(weights.handle, _ptr(rgba), _ptr(z), _ptr(mesh_sdf), Sa, _ptr(rgba_n), _ptr(sdf_n), Sn, _ptr(src, torch.int32), R,
+                                        _ptr(g_color), _ptr(g_depth), _ptr(g_alpha), _ptr(g_sdf), _ptr(d_a), _ptr(d_n), _ptr(d_beta), _stream()))
+    return d_a, d_n, d_beta
+
+
 def composite_merged(rgba_c, sdf_c, rgba_n, sdf_n, src, z_fine, beta, want_contrib=False):
     """Fine composite over [coarse samples | new importance samples] in merged depth order (vanerf_composite_merged)."""
     R, S = z_fine.shape

@@ -484,38 +484,74 @@ class PassGradient(torch.autograd.Function):
                 r1 = min(R, r0 + step)
                 # (1) the composites, differentiated at the HIP pass's own per-sample values: a small graph over (rays, samples, 5) tensors that
                 #     yields the gradient with respect to every sample's [alpha, sdf, r, g, b] (and to sigmoid_beta)
-                rc = c["rgba"][r0:r1].detach().clone().requires_grad_(True)
-                col, dep, acc, _ = composite(P, rc, o["z"][r0:r1], c["q_sdf"][r0:r1])
-                outs = {"tex_fg": col, "depth": dep, "alpha": acc}
-                per_sample = [rc]
                 cf = o.get("coarse_in_fine") if f is not None else None
-                if f is not None:
-                    rf = f["rgba"][r0:r1].detach().clone().requires_grad_(True)
-                    per_sample.append(rf)
-                    rgba_f, msdf = rf, f["q_sdf"][r0:r1]
-                    if o.get("fine_src") is not None:  # the pass re-used the coarse evaluations: merge [coarse | new] by the origin map
-                        src = o["fine_src"][r0:r1].long()
-                        take = torch.where(src >= 0, src, rc.shape[1] + (-src - 1))
-                        rcf = rc
-                        if cf is not None:  # (training noise: the coarse points carry other draws inside the fine batch)
-                            rcf = cf["rgba"][r0:r1].detach().clone().requires_grad_(True)
-                            per_sample.append(rcf)
-                        rgba_f = torch.gather(torch.cat([rcf, rf], 1), 1, take[..., None].expand(-1, -1, 5))
-                        msdf = torch.gather(torch.cat([c["q_sdf"][r0:r1], f["q_sdf"][r0:r1]], 1), 1, take)
-                    col, dep, acc, sdf = composite(P, rgba_f, o["z_fine"][r0:r1], msdf)
-                    outs.update({"tex_fg_fine": col, "depth_fine": dep, "alpha_fine": acc, "sdf": sdf})
-                pairs = []
-                for k, g in zip(keys, gouts):
-                    if g is None:
-                        continue
-                    # images are (1,3,h,w) / (1,h,w) over the patch's rays in row-major order: the chunk's rays are a slice of the flattened image
-                    gk = g.reshape(3, -1).t()[r0:r1] if k.startswith("tex_fg") else g.reshape(-1)[r0:r1]
-                    pairs.append((outs[k], gk))
-                mark("table graph + composite forward")
-                grads = torch.autograd.grad([a for a, _ in pairs], per_sample + loc, [b for _, b in pairs], allow_unused=True)
-                accumulate(grads[len(per_sample):])
-                mark("composite backward")
-                del outs, pairs, col, dep, acc
+                n_fine = 0 if f is None else (o["z_fine"].shape[1] if o.get("z_fine") is not None else f["rgba"].shape[1])
+                if spec.get("hip_backward") is not None and max(c["rgba"].shape[1], n_fine) <= 256:
+                    # vanerf_composite_backward: one launch per composite instead of this graph's ~500 (rays x samples x 5 element-wise kernels, a
+                    # cumprod whose backward blocks the host); sigmoid_beta is the handle's device copy (this step's parameter, clamped)
+                    from . import renderer as HR
+                    w0 = spec["hip_backward"]["w0"]
+                    gk = {}
+                    for k, g in zip(keys, gouts):
+                        if g is not None:
+                            gk[k] = (g.reshape(3, -1).t()[r0:r1] if k.startswith("tex_fg") else g.reshape(-1)[r0:r1]).contiguous()
+                    with torch.no_grad():
+                        d_rc, _, db = HR.composite_backward(w0, c["rgba"][r0:r1], o["z"][r0:r1], c["q_sdf"][r0:r1], gk.get("tex_fg"), gk.get("depth"), gk.get("alpha"))
+                        grads = [d_rc]
+                        if f is not None:
+                            gf = (gk.get("tex_fg_fine"), gk.get("depth_fine"), gk.get("alpha_fine"), gk.get("sdf"))
+                            if o.get("fine_src") is not None:
+                                rcf = c["rgba"] if cf is None else cf["rgba"]
+                                d_rcf, d_rf, db_f = HR.composite_backward(w0, rcf[r0:r1], o["z_fine"][r0:r1], c["q_sdf"][r0:r1], *gf, rgba_n=f["rgba"][r0:r1],
+                                                                          sdf_n=f["q_sdf"][r0:r1], src=o["fine_src"][r0:r1])
+                                if cf is None:
+                                    grads = [d_rc + d_rcf, d_rf]
+                                else:
+                                    grads = [d_rc, d_rf, d_rcf]
+                            else:
+                                d_rf, _, db_f = HR.composite_backward(w0, f["rgba"][r0:r1], o["z_fine"][r0:r1], f["q_sdf"][r0:r1], *gf)
+                                grads = [d_rc, d_rf]
+                            db = db.sum() + db_f.sum()
+                        else:
+                            db = db.sum()
+                        pb = P["sigmoid_beta"]
+                        g_beta = [None] * len(loc)
+                        g_beta[names.index("sigmoid_beta")] = (db * (pb.detach() >= 2e-3).to(db.dtype)).reshape(pb.shape)  # clamp(min = 2e-3)'s derivative
+                    accumulate(g_beta)
+                    per_sample = grads  # (only its length is used below)
+                    mark("composite backward (HIP)")
+                else:
+                    rc = c["rgba"][r0:r1].detach().clone().requires_grad_(True)
+                    col, dep, acc, _ = composite(P, rc, o["z"][r0:r1], c["q_sdf"][r0:r1])
+                    outs = {"tex_fg": col, "depth": dep, "alpha": acc}
+                    per_sample = [rc]
+                    if f is not None:
+                        rf = f["rgba"][r0:r1].detach().clone().requires_grad_(True)
+                        per_sample.append(rf)
+                        rgba_f, msdf = rf, f["q_sdf"][r0:r1]
+                        if o.get("fine_src") is not None:  # the pass re-used the coarse evaluations: merge [coarse | new] by the origin map
+                            src = o["fine_src"][r0:r1].long()
+                            take = torch.where(src >= 0, src, rc.shape[1] + (-src - 1))
+                            rcf = rc
+                            if cf is not None:  # (training noise: the coarse points carry other draws inside the fine batch)
+                                rcf = cf["rgba"][r0:r1].detach().clone().requires_grad_(True)
+                                per_sample.append(rcf)
+                            rgba_f = torch.gather(torch.cat([rcf, rf], 1), 1, take[..., None].expand(-1, -1, 5))
+                            msdf = torch.gather(torch.cat([c["q_sdf"][r0:r1], f["q_sdf"][r0:r1]], 1), 1, take)
+                        col, dep, acc, sdf = composite(P, rgba_f, o["z_fine"][r0:r1], msdf)
+                        outs.update({"tex_fg_fine": col, "depth_fine": dep, "alpha_fine": acc, "sdf": sdf})
+                    pairs = []
+                    for k, g in zip(keys, gouts):
+                        if g is None:
+                            continue
+                        # images are (1,3,h,w) / (1,h,w) over the patch's rays in row-major order: the chunk's rays are a slice of the flattened image
+                        gk = g.reshape(3, -1).t()[r0:r1] if k.startswith("tex_fg") else g.reshape(-1)[r0:r1]
+                        pairs.append((outs[k], gk))
+                    mark("table graph + composite forward")
+                    grads = torch.autograd.grad([a for a, _ in pairs], per_sample + loc, [b for _, b in pairs], allow_unused=True)
+                    accumulate(grads[len(per_sample):])
+                    mark("composite backward")
+                    del outs, pairs, col, dep, acc
                 # (2) the per-sample networks, one block of samples after the other (samples are independent): only one block's graph exists at a
                 #     time, which is what bounds the step's memory -- the coarse and the fine batch are never alive together
                 d_per = list(grads[:len(per_sample)])
