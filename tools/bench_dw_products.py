@@ -4,6 +4,8 @@ import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from vanerf_amd import hip_backward as HB
 npad = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+if len(sys.argv) > 2:
+    HB.SLICES = int(sys.argv[2])  # the block's samples are cut into this many separately accumulated parts
 ws = HB.Workspace(npad, "cuda")
 ws.xs.normal_(); ws.ys.normal_()
 def timed(fn, reps=10):
@@ -23,5 +25,5 @@ def unsliced():
     for lay in L["layers"]:
         ws.ys[lay["y_row"]:lay["y_row"] + lay["n_out"]] @ ws.xs[lay["x_row"]:lay["x_row"] + lay["n_slots"]].t()
 t_u = timed(unsliced)
-print(f"npad {npad}: vanerf_weight_products {t_k:.3f} ms ({flops / t_k / 1e9:.1f} TFLOP/s fp32, {byts / t_k / 1e9:.2f} TB/s of unique operand bytes)   "
+print(f"npad {npad}, {ws.slices} slices: vanerf_weight_products {t_k:.3f} ms ({flops / t_k / 1e9:.1f} TFLOP/s fp32, {byts / t_k / 1e9:.2f} TB/s of unique operand bytes)   "
       f"sliced baddbmm x 20 {t_t:.3f} ms   unsliced matmul x 20 {t_u:.3f} ms")

@@ -46,10 +46,10 @@ if PIPELINED:
         l = step()
     torch.cuda.synchronize(); ts.append((time.perf_counter() - t0) / 10); l = float(l)
 else:
-    for _ in range(5):
+    for _ in range(10):
         t0 = time.perf_counter(); l = step(); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
 with torch.no_grad():
     net.eval(); torch.cuda.synchronize(); t0 = time.perf_counter()
     net.train()
-print(f"training step (64x64 patch, 64+64 samples, encoders + HIP forward + backward + Adam): min {1e3 * min(ts):.1f} ms, loss {l:.4f}, "
+print(f"training step (64x64 patch, 64+64 samples, encoders + HIP forward + backward + Adam): min {1e3 * min(ts):.1f} ms, median {1e3 * sorted(ts)[len(ts) // 2]:.1f} ms, loss {l:.4f}, "
       f"peak memory {torch.cuda.max_memory_allocated() / 2**30:.2f} GiB")

@@ -41,22 +41,12 @@ __global__ __launch_bounds__(256, 1) void weight_products_kernel(const WpTask* _
     const WpTask T = tasks[ti];
     const int mt_n = (min(T.n_out, 32 * MG) + 31) / 32, nt_n = (min(T.n_slot, 32 * NG) + 31) / 32; // wave-uniform
     const long long per = npad / slices, s0 = (long long)slice * per;
-    // this lane's rows (clamped into the layer) and whether they exist
-    const float* ap[MG];
-    const float* bp[NG];
+    // whether this lane's operand rows exist in the layer (partial tiles: the loads below run over the next layer's rows, the operands are zeroed)
     bool av[MG], bv[NG];
 #pragma unroll
-    for (int m = 0; m < MG; ++m) {
-        const int r = 32 * m + i;
-        av[m] = r < T.n_out;
-        ap[m] = ys + (size_t)(T.y_row + (av[m] ? r : 0)) * (size_t)npad + s0 + 16 * kh;
-    }
+    for (int m = 0; m < MG; ++m) av[m] = 32 * m + i < T.n_out;
 #pragma unroll
-    for (int n = 0; n < NG; ++n) {
-        const int r = 32 * n + i;
-        bv[n] = r < T.n_slot;
-        bp[n] = xs + (size_t)(T.x_row + (bv[n] ? r : 0)) * (size_t)npad + s0 + 16 * kh;
-    }
+    for (int n = 0; n < NG; ++n) bv[n] = 32 * n + i < T.n_slot;
     f32x16 acc[MG][NG];
 #pragma unroll
     for (int m = 0; m < MG; ++m)
@@ -64,26 +54,47 @@ __global__ __launch_bounds__(256, 1) void weight_products_kernel(const WpTask* _
         for (int n = 0; n < NG; ++n)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
-    // One batch = 32 samples: a lane takes 64 contiguous bytes of its row (samples s + 16 kh .. + 15, four 16-byte loads), so the two lanes of a row
-    // consume a whole 128-byte line at once (16 bytes per visit fetched every line four times: 0.80 ms per block).  The next batch's 24 loads are in
-    // flight under this batch's 128 products (the kernel takes the whole register file: one wave per SIMD, 8 192 MFMA cycles per batch to hide them).
-    struct Batch { float4 a[MG][4], b[NG][4]; };
+    // One batch = 32 samples of the group's 64 + 128 operand rows.  Global side: instruction t fetches rows 8 t .. 8 t + 7, eight lanes per row, each lane
+    // 16 bytes -- whole 128-byte lines (a lane streaming its own row 16 bytes per visit fetched every line four times: 0.80 ms per block; 64 bytes per
+    // visit still left each instruction touching 32 lines: 0.65 ms).  The wave's own LDS window turns the rows around: lane (i, kh) reads samples 16 kh .. + 15
+    // of row i as its MFMA operands (rows padded to 144 bytes: the 16-byte reads of sixteen lanes cover all 64 banks once).  The next batch's loads
+    // are in flight under this batch's 128 products (the kernel takes the whole register file: one wave per SIMD).
+    const WRsrc ys_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ys), 0, (unsigned)(Y_ROWS * 4ll * npad), 0x00020000);
+    const WRsrc xs_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xs), 0, (unsigned)(X_ROWS * 4ll * npad), 0x00020000);
+    const unsigned row4 = (unsigned)npad * 4u;
+    const unsigned piece = 16u * (unsigned)(lane & 7) + 4u * (unsigned)s0;
+    const unsigned va = (unsigned)(T.y_row + (lane >> 3)) * row4 + piece, vb = (unsigned)(T.x_row + (lane >> 3)) * row4 + piece;
+    constexpr int ROW_F4 = 9, TA = 8 * MG / 2, TB = 8 * NG / 2; // float4 per LDS row (8 + 1 pad); load instructions of the A / B part (4 per tile)
+    extern __shared__ float4 s_rows[];
+    float4* const mine = s_rows + (threadIdx.x >> 6) * ((32 * (MG + NG)) * ROW_F4);
+    float4* const put = mine + (lane >> 3) * ROW_F4 + (lane & 7);   // + 8 t rows
+    const float4* const get = mine + i * ROW_F4 + 4 * kh;         // + 32 tile rows, + q
+    u32x4 g[TA + TB];
+    auto fetch = [&](unsigned sbyte) {
+#pragma unroll
+        for (int t = 0; t < TA; ++t) if (t / 4 < mt_n) g[t] = __builtin_amdgcn_raw_buffer_load_b128(ys_rs, va, (unsigned)(8 * t) * row4 + sbyte, 0);
+#pragma unroll
+        for (int t = 0; t < TB; ++t) if (t / 4 < nt_n) g[TA + t] = __builtin_amdgcn_raw_buffer_load_b128(xs_rs, vb, (unsigned)(8 * t) * row4 + sbyte, 0);
+    };
+    auto stage = [&]() { // registers -> LDS rows
+#pragma unroll
+        for (int t = 0; t < TA; ++t)
+            if (t / 4 < mt_n) put[(8 * t) * ROW_F4] = make_float4(__uint_as_float(g[t].x), __uint_as_float(g[t].y), __uint_as_float(g[t].z), __uint_as_float(g[t].w));
+#pragma unroll
+        for (int t = 0; t < TB; ++t)
+            if (t / 4 < nt_n) put[(32 * MG + 8 * t) * ROW_F4] = make_float4(__uint_as_float(g[TA + t].x), __uint_as_float(g[TA + t].y), __uint_as_float(g[TA + t].z), __uint_as_float(g[TA + t].w));
+    };
     const float4 zero4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    auto load = [&](Batch& B, long long s) {
+    auto products = [&]() {
+        float4 a[MG][4], b[NG][4];
 #pragma unroll
         for (int m = 0; m < MG; ++m)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) B.a[m][q] = (m < mt_n) ? reinterpret_cast<const float4*>(ap[m] + s)[q] : zero4;
+            for (int q = 0; q < 4; ++q) a[m][q] = (m < mt_n && av[m]) ? get[(32 * m) * ROW_F4 + q] : zero4;
 #pragma unroll
         for (int n = 0; n < NG; ++n)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) B.b[n][q] = (n < nt_n) ? reinterpret_cast<const float4*>(bp[n] + s)[q] : zero4;
-    };
-    auto products = [&](Batch& B) {
-#pragma unroll
-        for (int m = 0; m < MG; ++m) if (!av[m]) { B.a[m][0] = zero4; B.a[m][1] = zero4; B.a[m][2] = zero4; B.a[m][3] = zero4; }
-#pragma unroll
-        for (int n = 0; n < NG; ++n) if (!bv[n]) { B.b[n][0] = zero4; B.b[n][1] = zero4; B.b[n][2] = zero4; B.b[n][3] = zero4; }
+            for (int q = 0; q < 4; ++q) b[n][q] = (n < nt_n && bv[n]) ? get[(32 * (MG + n)) * ROW_F4 + q] : zero4;
 #pragma unroll
         for (int m = 0; m < MG; ++m) {
             if (m >= mt_n) break;
@@ -92,22 +103,19 @@ __global__ __launch_bounds__(256, 1) void weight_products_kernel(const WpTask* _
                 if (n >= nt_n) break;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(B.a[m][q].x, B.b[n][q].x, acc[m][n], 0, 0, 0);
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(B.a[m][q].y, B.b[n][q].y, acc[m][n], 0, 0, 0);
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(B.a[m][q].z, B.b[n][q].z, acc[m][n], 0, 0, 0);
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(B.a[m][q].w, B.b[n][q].w, acc[m][n], 0, 0, 0);
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m][q].x, b[n][q].x, acc[m][n], 0, 0, 0);
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m][q].y, b[n][q].y, acc[m][n], 0, 0, 0);
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m][q].z, b[n][q].z, acc[m][n], 0, 0, 0);
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m][q].w, b[n][q].w, acc[m][n], 0, 0, 0);
                 }
             }
         }
     };
-    Batch B0, B1;
-    load(B0, 0);
-    for (long long s = 0; s < per; s += 64) {
-        if (s + 32 < per) load(B1, s + 32);
-        products(B0);
-        if (s + 32 >= per) break;
-        if (s + 64 < per) load(B0, s + 64);
-        products(B1);
+    fetch(0);
+    for (long long s = 0; s < per; s += 32) {
+        stage();                                   // (LDS operations of a wave execute in order: the previous batch's reads are ahead of these writes)
+        if (s + 32 < per) fetch((unsigned)(4 * (s + 32)));
+        products();
     }
     // accumulate: register r of lane l holds row (r & 3) + 8 (r >> 2) + 4 (l >> 5), column l & 31 of the tile
     float* out = dw + T.dw_off + (size_t)slice * T.dw_layer;
@@ -198,7 +206,11 @@ extern "C" int vanerf_weight_products(const float* xs, const float* ys, int64_t 
         HIP_CHECK(hipGetDevice(&device));
         const DevTable& t = device_table(device, layout_slices);
         const unsigned blocks = (unsigned)((t.n + 3) / 4) * (unsigned)slices;
-        hipLaunchKernelGGL(weight_products_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, t.dev, t.n, xs, ys, (long long)npad, slices, dw);
+        constexpr int lds = 4 * 32 * (MG + NG) * 9 * 16; // four waves x 192 rows x 144 bytes
+        static_assert(lds <= 160 * 1024, "the four waves' windows fit the CU's LDS");
+        if ((long long)X_ROWS * 4 * npad >= (1ll << 32)) throw_error("vanerf_weight_products: spills of more than 4 GB (32-bit offsets)");
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(weight_products_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        hipLaunchKernelGGL(weight_products_kernel, dim3(blocks), dim3(256), lds, (hipStream_t)stream, t.dev, t.n, xs, ys, (long long)npad, slices, dw);
         HIP_CHECK(hipGetLastError());
     });
 }
