@@ -316,6 +316,9 @@ int vanerf_render_pass(const VanerfWeights* w, const VanerfFrame* frame, const V
  * slices of the table instead of contended global atomics.                                                                               */
 /* g_ld: floats between consecutive rows of g (0 = C: packed rows).                                                                        */
 int vanerf_scatter_add_rows(const int32_t* idx, const float* w, const float* g, int64_t g_ld, int64_t n, int C, float* table, int R, void* stream);
+/* two sources into one table in one launch (the nearest and the twin vertex row of a sample): table[idx[i]] += w[i] g[i], table[idx2[i]] += w2[i] g2[i] */
+int vanerf_scatter_add_rows2(const int32_t* idx, const float* w, const float* g, const int32_t* idx2, const float* w2, const float* g2, int64_t g_ld,
+                             int64_t n, int C, float* table, int R, void* stream);
 /* the same with FOUR (index, weight) pairs per sample, idx4 / w4 = [4][ld] (ld >= n): the backward of a bilinear tap gather (src/utils.py:136-151) */
 int vanerf_scatter_add_taps(const int32_t* idx4, const float* w4, int64_t ld, const float* g, int64_t g_ld, int64_t n, int C, float* table, int R,
                             void* stream);

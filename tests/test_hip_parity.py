@@ -1127,6 +1127,15 @@ def test_scatter_add_rows(R):
             want = base.double().index_add(0, idx.long(), (val if weights is None else val * weights[:, None]).double())
             got = R.scatter_add_rows(base.clone(), idx, val, weights)
             assert (got.double() - want).abs().max() <= 1e-5 * (1.0 + want.abs().max()), (rows, C)
+    # two sources into one table in one launch (nearest and twin vertex rows), rows read in place from wider row-major tensors (29 of 32 columns)
+    n, rows = 70001, 1558
+    idx, idx2 = (torch.randint(0, rows, (n,), device="cuda", generator=g, dtype=torch.int32) for _ in range(2))
+    wide, wide2 = (torch.randn(n, 32, device="cuda", generator=g) for _ in range(2))
+    w, w2 = (torch.rand(n, device="cuda", generator=g) for _ in range(2))
+    base = torch.randn(rows, 29, device="cuda", generator=g)
+    want = base.double().index_add(0, idx.long(), (wide[:, :29] * w[:, None]).double()).index_add(0, idx2.long(), (wide2[:, :29] * w2[:, None]).double())
+    got = R.scatter_add_rows2(base.clone(), idx, wide[:, :29], w, idx2, wide2[:, :29], w2)
+    assert (got.double() - want).abs().max() <= 1e-5 * (1.0 + want.abs().max())
     idx = torch.tensor([0, 7, -1, 5, 2], device="cuda", dtype=torch.int32)  # rows outside the table contribute nothing
     got = R.scatter_add_rows(torch.zeros(5, 2, device="cuda"), idx, torch.ones(5, 2, device="cuda"))
     assert got.sum().item() == 4.0 and got[0, 0].item() == 1.0 and got[2, 1].item() == 1.0  # rows 7, -1 and 5 lie outside a 5-row table

@@ -19,7 +19,8 @@ constexpr int SC_BLOCK = 256;
 // TAPS rows per sample (idx / w are [TAPS][ld]): the four bilinear taps of a pixel feature read its gradient row once
 template <int CS, int TAPS = 1>
 __global__ __launch_bounds__(SC_BLOCK) void scatter_rows_kernel(const int32_t* __restrict__ idx, const float* __restrict__ w, const float* __restrict__ g,
-                                                                long long n, int C, int R, float* __restrict__ table, long long ld, long long g_ld)
+                                                                long long n, int C, int R, float* __restrict__ table, long long ld, long long g_ld,
+                                                                const int32_t* __restrict__ idx2, const float* __restrict__ w2, const float* __restrict__ g2)
 {
     extern __shared__ float s_tab[];
     const int c0 = blockIdx.y * CS;
@@ -41,6 +42,14 @@ __global__ __launch_bounds__(SC_BLOCK) void scatter_rows_kernel(const int32_t* _
                 if (w) v *= w[i + k * ld];
                 atomicAdd(&s_tab[r * CS + cl], v);
             }
+            if (TAPS == 1 && idx2) { // a second (index, weight, row) source into the same table: the nearest and the twin vertex row of a sample
+                const int r = idx2[i];
+                if ((unsigned)r < (unsigned)R) {
+                    float v = g2[i * g_ld + c0 + cl];
+                    if (w2) v *= w2[i];
+                    atomicAdd(&s_tab[r * CS + cl], v);
+                }
+            }
         }
     __syncthreads();
     for (int k = threadIdx.x; k < R * CS; k += SC_BLOCK) {
@@ -56,13 +65,24 @@ __global__ __launch_bounds__(SC_BLOCK) void scatter_rows_kernel(const int32_t* _
 // for a plain gradient).  Rows outside [0, R) are ignored.
 namespace {
 void scatter_rows(const int32_t* idx, const float* w, const float* g, int64_t g_ld, int64_t n, int C, float* table, int R, int taps, int64_t ld,
-                  void* stream);
+                  void* stream, const int32_t* idx2 = nullptr, const float* w2 = nullptr, const float* g2 = nullptr);
 }
 
 extern "C" int vanerf_scatter_add_rows(const int32_t* idx, const float* w, const float* g, int64_t g_ld, int64_t n, int C, float* table, int R,
                                        void* stream)
 {
     return guarded([&] { scatter_rows(idx, w, g, g_ld, n, C, table, R, 1, 0, stream); });
+}
+
+// two sources into one table in one launch: table[idx[i]] += w[i] g[i], table[idx2[i]] += w2[i] g2[i] (g, g2 with the same row distance g_ld): the
+// nearest and the twin vertex row of every sample -- one pass over the LDS slices instead of two
+extern "C" int vanerf_scatter_add_rows2(const int32_t* idx, const float* w, const float* g, const int32_t* idx2, const float* w2, const float* g2,
+                                        int64_t g_ld, int64_t n, int C, float* table, int R, void* stream)
+{
+    return guarded([&] {
+        if (!idx2 || !g2) throw_error("vanerf_scatter_add_rows2: null argument");
+        scatter_rows(idx, w, g, g_ld, n, C, table, R, 1, 0, stream, idx2, w2, g2);
+    });
 }
 
 // the same with FOUR (index, weight) pairs per sample, idx4 / w4 = [4][ld] (ld >= n): table[idx4[k][i]] += w4[k][i] * g[i] for k < 4 -- the
@@ -78,7 +98,7 @@ extern "C" int vanerf_scatter_add_taps(const int32_t* idx4, const float* w4, int
 
 namespace {
 void scatter_rows(const int32_t* idx, const float* w, const float* g, int64_t g_ld, int64_t n, int C, float* table, int R, int taps, int64_t ld,
-                  void* stream)
+                  void* stream, const int32_t* idx2, const float* w2, const float* g2)
 {
     {
         if (n == 0) return;
@@ -104,7 +124,7 @@ void scatter_rows(const int32_t* idx, const float* w, const float* g, int64_t g_
 #define LAUNCH1(CS, TAPS)                                                                                                                  \
     do {                                                                                                                                   \
         if (lds > 64 * 1024) HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(scatter_rows_kernel<CS, TAPS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL((scatter_rows_kernel<CS, TAPS>), grid, dim3(SC_BLOCK), lds, st, idx, w, g, (long long)n, C, R, table, (long long)ld, (long long)g_ld); \
+        hipLaunchKernelGGL((scatter_rows_kernel<CS, TAPS>), grid, dim3(SC_BLOCK), lds, st, idx, w, g, (long long)n, C, R, table, (long long)ld, (long long)g_ld, idx2, w2, g2); \
     } while (0)
 #define LAUNCH(CS) do { if (taps == 4) LAUNCH1(CS, 4); else LAUNCH1(CS, 1); } while (0)
         switch (cs) {

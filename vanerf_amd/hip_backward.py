@@ -236,8 +236,7 @@ class InputScatter:
             idx, w = self.taps[name]
             R.scatter_add_taps(self.acc[name], idx, w, sl, g[key])
         for name, kn, kt in (("vtab0", "nn0", "tw0"), ("vtab1", "nn1", "tw1"), ("table29", "row_nn", "row_tw")):
-            R.scatter_add_rows(self.acc[name], self.knn[sl], g[kn], self.vn[sl])
-            R.scatter_add_rows(self.acc[name], self.twin[sl], g[kt], self.vt[sl])
+            R.scatter_add_rows2(self.acc[name], self.knn[sl], g[kn], self.vn[sl], self.twin[sl], g[kt], self.vt[sl])
 
     def map_gradient(self, name):
         """(1, C, H, W) gradient of a feature map from its pixel taps."""

@@ -806,6 +806,19 @@ def scatter_add_taps(table, idx4, w4, sl, g):
     return table
 
 
+def scatter_add_rows2(table, idx, g, w, idx2, g2, w2):
+    """table[idx[i]] += w[i] g[i] and table[idx2[i]] += w2[i] g2[i] in one launch (vanerf_scatter_add_rows2)."""
+    n, C = g.shape
+    assert table.shape[1] == C and idx.shape == (n,) and idx2.shape == (n,) and g2.shape == g.shape and table.is_contiguous()
+    g, g2 = _rows(g), _rows(g2)
+    if table.shape[0] * 4 > 128 * 1024 or g.stride(0) != g2.stride(0):
+        scatter_add_rows(table, idx, g, w)
+        return scatter_add_rows(table, idx2, g2, w2)
+    check(lib.vanerf_scatter_add_rows2(_ptr(idx, torch.int32), _ptr(w, torch.float32), _rows_ptr(g), _ptr(idx2, torch.int32), _ptr(w2, torch.float32), _rows_ptr(g2),
+                                       g.stride(0), n, C, _ptr(table, torch.float32), table.shape[0], _stream()))
+    return table
+
+
 def scatter_add_rows(table, idx, g, w=None):
     """table[idx[i]] += w[i] * g[i] (vanerf_scatter_add_rows): the backward of a row gather over ~1e6 samples into a table of ~1e3..1e4 rows."""
     n, C = g.shape
