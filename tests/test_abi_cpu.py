@@ -100,3 +100,24 @@ def test_backward_spill_layout_is_consistent(ffi, hot_weights):
     assert ffi.lib.vanerf_layer_slots(20, None, 0) < 0 and ffi.lib.vanerf_layer_slots(-1, None, 0) < 0
     buf = (ctypes.c_int32 * 4)()
     assert ffi.lib.vanerf_layer_slots(8, ctypes.cast(buf, ctypes.c_void_p), 4) < 0  # capacity below the layer's slot count
+
+
+def test_training_entry_points_validate_their_arguments(ffi):
+    """The round-3 training entry points refuse null / inconsistent arguments with an error code before anything touches a GPU."""
+    lib = ffi.lib
+    n = ctypes.c_int64()
+    assert lib.vanerf_weight_products_size(ctypes.byref(n)) == 0 and n.value > 100000
+    assert lib.vanerf_weight_products(None, None, 65536, 64, 64, None, None) == -22 and b"null" in lib.vanerf_last_error()
+    p = ctypes.c_void_p(8)
+    assert lib.vanerf_weight_products(p, p, 1000, 64, 64, p, None) == -22 and b"multiple of 32" in lib.vanerf_last_error()
+    assert lib.vanerf_weight_products(p, p, 65536, 128, 64, p, None) == -22  # more slices than the accumulator was laid out for
+    assert lib.vanerf_composite_backward(None, p, p, p, 8, None, None, 0, None, 4, None, None, None, None, p, None, None, None) == -22
+    assert lib.vanerf_weights_update(None, None, None, None) == -22 and b"null" in lib.vanerf_last_error()
+    o, c, s = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    assert lib.vanerf_ig_tensor(9, ctypes.byref(o), ctypes.byref(c), ctypes.byref(s)) < 0
+    seen = []
+    for which in range(9):
+        assert lib.vanerf_ig_tensor(which, ctypes.byref(o), ctypes.byref(c), ctypes.byref(s)) == 9
+        assert c.value <= s.value
+        seen.append((o.value, s.value))
+    assert all(a[0] + a[1] == b[0] for a, b in zip(seen, seen[1:])) and seen[-1][0] + seen[-1][1] == 288  # the tensors tile the 288 floats per sample

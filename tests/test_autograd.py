@@ -420,3 +420,60 @@ def test_weight_products_kernel_against_matrix_products(npad):
         scale = want.abs().max().item()
         assert (have - want).abs().max().item() <= 2e-5 * scale + 1e-4, (li, (have - want).abs().max().item(), scale)
         assert (have - want).abs().max().item() <= 2.0 * (ref - want).abs().max().item() + 1e-4 * scale, li  # no worse than the library products
+
+
+@pytest.mark.parametrize("S,Sn", [(16, 0), (64, 0), (128, 0), (200, 0), (64, 64), (40, 24), (8, 8)])
+def test_composite_backward_against_autograd(S, Sn):
+    """vanerf_composite_backward (one wave per ray; dL/dsigma from a suffix scan, no division by 1 - c) against torch.autograd through
+    torch_graph.composite in fp64: single table and the merged [coarse | new] order with its origin map, opaque samples (c = 1 exactly in fp32:
+    the case torch.cumprod's backward branches for), upstream gradients on every output or only on some, sigmoid_beta's share."""
+    from vanerf_amd import renderer as R, torch_graph as G
+    g = torch.Generator(device="cuda").manual_seed(100 * S + Sn)
+    rays = 257
+    sd = synth.make_full_weights(0)
+    sd["sigmoid_beta"] = torch.tensor([0.05])
+    w = R.PackedWeights(sd, mode="fp32")
+    St = S + Sn
+    z = torch.sort(torch.rand(rays, St, device="cuda", generator=g) * 0.3 + 0.4, dim=1)[0].contiguous()
+    ra = torch.randn(rays, S, 5, device="cuda", generator=g) * 0.05
+    ma = torch.randn(rays, S, device="cuda", generator=g) * 0.02
+    ra[:, S // 2, 0] = -5.0   # an opaque sample in every ray: sigma dist ~ 1e3, c = 1 exactly
+    ra[::7, :, 0] = 5.0       # rays that hit nothing: sigma ~ 0 everywhere, acc ~ 0
+    rn = mn = src = None
+    if Sn:
+        rn = torch.randn(rays, Sn, 5, device="cuda", generator=g) * 0.05
+        mn = torch.randn(rays, Sn, device="cuda", generator=g) * 0.02
+        perm = torch.argsort(torch.rand(rays, St, device="cuda", generator=g), dim=1)  # merged position -> table entry
+        src = torch.where(perm < S, perm, -(perm - S) - 1).to(torch.int32).contiguous()
+    for with_all in (True, False):
+        gc = torch.randn(rays, 3, device="cuda", generator=g)
+        gd, ga, gs = (torch.randn(rays, device="cuda", generator=g) for _ in range(3))
+        if not with_all:
+            gd = gs = None
+        d_a, d_n, d_beta = R.composite_backward(w, ra, z, ma, gc, gd, ga, gs, rgba_n=rn, sdf_n=mn, src=src)
+        # the same through autograd, fp64
+        beta = torch.tensor([0.05], dtype=torch.float64, device="cuda", requires_grad=True)
+        xa = ra.double().requires_grad_(True)
+        leaves = [xa, beta]
+        if Sn:
+            xn = rn.double().requires_grad_(True)
+            leaves.append(xn)
+            take = torch.where(src >= 0, src.long(), S + (-src.long() - 1))
+            rgba = torch.gather(torch.cat([xa, xn], 1), 1, take[..., None].expand(-1, -1, 5))
+            msdf = torch.gather(torch.cat([ma, mn], 1).double(), 1, take)
+        else:
+            rgba, msdf = xa, ma.double()
+        col, dep, acc, sdf = G.composite({"sigmoid_beta": beta}, rgba, z.double(), msdf)
+        loss = (col * gc.double()).sum() + (acc * ga.double()).sum()
+        if with_all:
+            loss = loss + (dep * gd.double()).sum() + (sdf * gs.double()).sum()
+        grads = torch.autograd.grad(loss, leaves)
+        def close(have, want, what):
+            scale = want.abs().max().item() + 1e-12
+            err = (have.double() - want).abs().max().item()
+            assert err <= 2e-4 * scale + 1e-6, (what, S, Sn, with_all, err, scale)
+        close(d_a, grads[0], "d_rgba")
+        if Sn:
+            close(d_n, grads[2], "d_rgba_n")
+        assert abs(d_beta.double().sum().item() - grads[1].item()) <= 2e-3 * abs(grads[1].item()) + 1e-3, (d_beta.double().sum().item(), grads[1].item())
+        assert torch.isfinite(d_a).all() and torch.isfinite(d_beta).all()
