@@ -243,6 +243,12 @@ int vanerf_composite_merged(const float* rgba_c, const float* mesh_sdf_c, int Sc
                             float* alpha, float* sdf, float* contrib, void* stream);
 /* Either composite with sigmoid_beta read from the weight handle's device copy (what vanerf_render_pass does; after vanerf_weights_update the host
  * never sees the value): rgba_n == NULL composites the Sa samples per ray of one table, otherwise [table | rgba_n table] in merged order (src).   */
+/* eval_func (src/model.py:1140-1160) on raw outputs of vanerf_query_samples(raw = 1): [sdf_pred, rad, r, g, b] -> [alpha, sdf, r, g, b] with the validity
+ * flags and optional per-sample noise, the arithmetic of the kernel's own epilogue (same bits).  src == NULL: R x Sa entries of table a, noise[i] per entry;
+ * otherwise noise[r][p] belongs to position p of ray r's merged order and src names the entry (>= 0 table a, < 0 entry ~src of table b), each written once.
+ * The outputs may be the raw tables themselves.  With training noise a pass evaluates the networks once per point and runs this once per set of draws.     */
+int vanerf_eval_func(const float* raw_a, const uint8_t* valid_a, const float* raw_b, const uint8_t* valid_b, const int32_t* src, const float* noise,
+                     int Sa, int Sb, int R, float invalid_sdf, float* rgba_a, float* rgba_b, void* stream);
 int vanerf_composite_handle(const VanerfWeights* w, const float* rgba, const float* z, const float* mesh_sdf, int Sa, const float* rgba_n,
                             const float* mesh_sdf_n, int Sn, const int32_t* src, int R, float* color, float* depth, float* alpha, float* sdf,
                             float* contrib, void* stream);
@@ -281,8 +287,10 @@ typedef struct {
     float bounds[6];           /* {min xyz, max xyz} of the mesh bounding box (config['bounds']) */
     int Sc, Sf;                /* sample_per_ray_c, sample_per_ray_f */
     int fine;                  /* config['fine'] */
-    int reuse_coarse;          /* 1: the fine composite re-uses the coarse evaluations (only the Sf new samples are evaluated; identical bits);
-                                  forced to 0 when noise_c is given (the reference draws fresh noise for re-evaluated samples) */
+    int reuse_coarse;          /* 1: the fine composite re-uses the coarse evaluations (only the Sf new samples are evaluated; identical bits).  With
+                                  noise_c / noise_f (training) the networks still run once per point: raw outputs, then eval_func with the coarse draws
+                                  and again with the fine batch's draws (vanerf_eval_func) -- the noise is added to the networks' OUTPUT
+                                  (src/model.py:1155-1156), so the bits are those of re-evaluating all Sc + Sf samples */
     const float* t_lin_c;      /* th.linspace(0, 1, Sc) (device) */
     const float* t_lin_f;      /* th.linspace(0, 1, Sf) (device); used when u == NULL (uniform=True) */
     const float* jitter;       /* [R][Sc] stratification draws or NULL (uniform=True) */
@@ -305,6 +313,7 @@ typedef struct {               /* all device pointers; R = nx * ny */
     float* z_fine;             /* [R][Sc+Sf] merged depths, or NULL */
 } VanerfPassOut;
 
+/* reuse_coarse: 0, 1 as VanerfPassDesc.reuse_coarse; 2 = re-use under per-sample noise (desc->reuse_coarse with noise_c given: more temporaries) */
 int64_t vanerf_render_pass_scratch(int n_rays, int Sc, int Sf, int fine, int reuse_coarse);
 int vanerf_render_pass(const VanerfWeights* w, const VanerfFrame* frame, const VanerfMeshAccel* accel, const float* verts, int nv,
                        const int32_t* faces, int nf, const VanerfPassDesc* desc, const VanerfPassOut* out, void* scratch, int64_t scratch_bytes,

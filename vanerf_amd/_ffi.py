@@ -104,6 +104,7 @@ _SIGS = {
     "vanerf_query_order_scratch": (c_int64, [c_int64]),
     "vanerf_composite": (c_int, [_FP, _FP, _FP, c_int, c_int, c_float, _FP, _FP, _FP, _FP, _FP, c_void_p]),
     "vanerf_composite_merged": (c_int, [_FP, _FP, c_int, _FP, _FP, c_int, _FP, _FP, c_int, c_float, _FP, _FP, _FP, _FP, _FP, c_void_p]),
+    "vanerf_eval_func": (c_int, [_FP, _FP, _FP, _FP, _FP, _FP, c_int, c_int, c_int, c_float, _FP, _FP, c_void_p]),
     "vanerf_composite_handle": (c_int, [c_void_p, _FP, _FP, _FP, c_int, _FP, _FP, c_int, _FP, c_int, _FP, _FP, _FP, _FP, _FP, c_void_p]),
     "vanerf_composite_backward": (c_int, [c_void_p, _FP, _FP, _FP, c_int, _FP, _FP, c_int, _FP, c_int, _FP, _FP, _FP, _FP, _FP, _FP, _FP, c_void_p]),
     "vanerf_importance_merge": (c_int, [_FP, _FP, _FP, _FP, c_int, c_int, c_int, _FP, _FP, _FP, _FP, c_void_p]),

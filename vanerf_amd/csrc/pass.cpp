@@ -26,6 +26,8 @@ struct Carver {
 // The temporaries of a pass.  Laid out by the same code for the size query (base == NULL) and for the run.
 struct Layout {
     float *rays_d, *cam_pos, *near, *far, *pts, *q_sdf_c, *rgba_c, *contrib, *z_new, *q_sdf_f, *rgba_f, *z_fine, *color_f3, *s1;
+    float *raw_c, *rgba_cf;      // noisy reuse: the coarse points' raw outputs, and their eval_func with the fine batch's draws
+    uint8_t *valid_c, *valid_f;
     uint8_t *q_vis;
     int32_t *knn, *order, *src;
     unsigned long long* queue_words; // work-queue heads of the pass's four big launches (mesh query and per-sample networks, coarse and fine)
@@ -33,6 +35,8 @@ struct Layout {
     int64_t order_scratch_bytes, total;
 };
 
+// reuse: 0 the fine march evaluates all Sc + Sf samples; 1 it evaluates the Sf new ones and the composite gathers the coarse evaluations;
+// 2 the same under per-sample noise: raw network outputs once per point, eval_func once per set of draws (vanerf_eval_func)
 Layout carve(void* base, int R, int Sc, int Sf, int fine, int reuse)
 {
     Carver c(base);
@@ -58,6 +62,12 @@ Layout carve(void* base, int R, int Sc, int Sf, int fine, int reuse)
         L.z_fine = c.take<float>((int64_t)R * (Sc + Sf));
         L.q_sdf_f = c.take<float>(nf);
         L.rgba_f = c.take<float>(5 * nf);
+        if (reuse == 2) {
+            L.raw_c = c.take<float>(5 * nc);
+            L.rgba_cf = c.take<float>(5 * nc);
+            L.valid_c = c.take<uint8_t>(nc);
+            L.valid_f = c.take<uint8_t>(nf);
+        }
     }
     L.color_f3 = c.take<float>(3LL * R); // stand-ins for optional outputs the caller did not ask for
     L.s1 = c.take<float>(4LL * R);
@@ -94,7 +104,7 @@ extern "C" int vanerf_render_pass(const VanerfWeights* w, const VanerfFrame* fra
         if (!o.index || !o.hit || !o.z || !o.color || !o.depth || !o.alpha) throw_error("vanerf_render_pass: a coarse output pointer is null");
         if (!d.t_lin_c || (fine && !d.u && !d.t_lin_f)) throw_error("vanerf_render_pass: linspace tables missing");
         if (fine && d.noise_c && !d.noise_f) throw_error("vanerf_render_pass: noise_c without noise_f");
-        const int reuse = d.reuse_coarse && !d.noise_c;
+        const int reuse = !d.reuse_coarse || !fine ? 0 : d.noise_c ? 2 : 1;
         const Layout L = carve(scratch, R, Sc, Sf, fine, reuse);
         if (scratch_bytes < L.total) throw_error("vanerf_render_pass: scratch of %lld bytes, %lld needed (vanerf_render_pass_scratch)", (long long)scratch_bytes, (long long)L.total);
         // a1-a4: pixel grid, rays, bbox clip, coarse depths
@@ -109,7 +119,7 @@ extern "C" int vanerf_render_pass(const VanerfWeights* w, const VanerfFrame* fra
                                 d.jitter, o.index, L.rays_d, L.cam_pos, L.near, L.far, o.hit, o.z, stream), "ray setup");
         // one march: points, mesh query (+ 1-NN), validity partition, per-sample networks
         int marches = 0; // every launch with a work queue gets a word of its own from the scratch block (nothing is shared between launches in flight)
-        auto march = [&](const float* z, int S, const float* noise, float* q_sdf, float* rgba) {
+        auto march = [&](const float* z, int S, const float* noise, float* q_sdf, float* rgba, uint8_t* valid_raw = nullptr) { // valid_raw: raw outputs + flags
             unsigned long long* const qw = L.queue_words + 2 * marches++;
             const int64_t n = (int64_t)R * S;
             ok(vanerf_sample_points(L.rays_d, L.cam_pos, z, R, S, L.pts, stream), "sample points");
@@ -121,9 +131,14 @@ extern "C" int vanerf_render_pass(const VanerfWeights* w, const VanerfFrame* fra
                 ok(vanerf_query_order(frame, L.pts, n, L.order, L.order_scratch, L.order_scratch_bytes, stream), "validity partition");
                 order = L.order;
             }
-            ok(vanerf_query_samples(w, frame, L.pts, q_sdf, L.q_vis, L.knn, noise, order, 0, n, rgba, nullptr, qw + 1, stream), "per-sample networks");
+            ok(vanerf_query_samples(w, frame, L.pts, q_sdf, L.q_vis, L.knn, noise, order, valid_raw ? 1 : 0, n, rgba, valid_raw, qw + 1, stream), "per-sample networks");
         };
-        march(o.z, Sc, d.noise_c, L.q_sdf_c, L.rgba_c);
+        if (reuse == 2) { // the networks once per point; eval_func with the coarse draws here, with the fine batch's draws below
+            march(o.z, Sc, nullptr, L.q_sdf_c, L.raw_c, L.valid_c);
+            ok(vanerf_eval_func(L.raw_c, L.valid_c, nullptr, nullptr, nullptr, d.noise_c, Sc, 0, R, frame->invalid_sdf, L.rgba_c, nullptr, stream), "eval_func (coarse)");
+        } else {
+            march(o.z, Sc, d.noise_c, L.q_sdf_c, L.rgba_c);
+        }
         composite_with_handle(w, L.rgba_c, o.z, L.q_sdf_c, nullptr, nullptr, nullptr, Sc, 0, R, o.color, o.depth, o.alpha, L.s1, L.contrib, stream);
         if (!fine) return;
         float* z_fine = o.z_fine ? o.z_fine : L.z_fine;
@@ -132,7 +147,12 @@ extern "C" int vanerf_render_pass(const VanerfWeights* w, const VanerfFrame* fra
         float* af = o.alpha_fine ? o.alpha_fine : L.s1 + 2LL * R;
         float* sf = o.sdf ? o.sdf : L.s1 + 3LL * R;
         ok(vanerf_importance_merge(L.contrib, o.z, d.u, d.u ? nullptr : d.t_lin_f, R, Sc, Sf, L.z_new, z_fine, L.src, nullptr, stream), "importance sampling");
-        if (reuse) {
+        if (reuse == 2) {
+            march(L.z_new, Sf, nullptr, L.q_sdf_f, L.rgba_f, L.valid_f);
+            // noise_f holds one draw per position of the merged order (the reference draws them for the re-evaluated fine batch, src/model.py:1155-1156)
+            ok(vanerf_eval_func(L.raw_c, L.valid_c, L.rgba_f, L.valid_f, L.src, d.noise_f, Sc, Sf, R, frame->invalid_sdf, L.rgba_cf, L.rgba_f, stream), "eval_func (fine)");
+            composite_with_handle(w, L.rgba_cf, z_fine, L.q_sdf_c, L.rgba_f, L.q_sdf_f, L.src, Sc, Sf, R, cf, df, af, sf, nullptr, stream);
+        } else if (reuse) {
             march(L.z_new, Sf, nullptr, L.q_sdf_f, L.rgba_f);
             composite_with_handle(w, L.rgba_c, z_fine, L.q_sdf_c, L.rgba_f, L.q_sdf_f, L.src, Sc, Sf, R, cf, df, af, sf, nullptr, stream);
         } else {

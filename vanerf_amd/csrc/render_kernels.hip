@@ -485,6 +485,52 @@ static void launch_composite(const float* rgba, const float* z, const float* msd
     HIP_CHECK(hipGetLastError());
 }
 
+// eval_func (src/model.py:1140-1160) on raw network outputs [sdf_pred, rad, r, g, b] -> [alpha, sdf, r, g, b]: alpha = mask relu(rad + noise),
+// sdf = mask sdf_pred + (1 - mask) invalid_sdf -- the arithmetic of query_kernel's own epilogue, so the same bits.  With per-sample noise (training) the
+// networks are evaluated once per point (raw) and this runs once per set of draws: src == NULL: entry i of table a with noise[i]; otherwise position p of
+// a ray's merged order carries noise[r][p] and names its entry (src >= 0: table a, < 0: entry ~src of table b); every entry is written once
+// (rgba_a / rgba_b may be the raw tables themselves).
+__global__ __launch_bounds__(256) void eval_func_kernel(const float* __restrict__ raw_a, const uint8_t* __restrict__ valid_a, const float* __restrict__ raw_b,
+                                                        const uint8_t* __restrict__ valid_b, const int32_t* __restrict__ src, const float* __restrict__ noise,
+                                                        int Sa, int Sb, long long n, float invalid_sdf, float* __restrict__ rgba_a, float* __restrict__ rgba_b)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int S = Sa + Sb;
+    const long long r = i / S;
+    const float* q;
+    float* o;
+    float mask;
+    if (src) {
+        const int k = src[i];
+        if (k >= 0) { const long long e = r * Sa + k; q = raw_a + 5 * e; o = rgba_a + 5 * e; mask = valid_a[e] ? 1.0f : 0.0f; }
+        else { const long long e = r * Sb + (~k); q = raw_b + 5 * e; o = rgba_b + 5 * e; mask = valid_b[e] ? 1.0f : 0.0f; }
+    } else {
+        q = raw_a + 5 * i; o = rgba_a + 5 * i; mask = valid_a[i] ? 1.0f : 0.0f;
+    }
+    const float q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], q4 = q[4];
+    float rad = q1;
+    if (noise) rad += noise[i];
+    o[0] = mask * fmaxf(rad, 0.0f);
+    o[1] = mask * q0 + (1.0f - mask) * invalid_sdf;
+    o[2] = q2; o[3] = q3; o[4] = q4;
+}
+
+extern "C" int vanerf_eval_func(const float* raw_a, const uint8_t* valid_a, const float* raw_b, const uint8_t* valid_b, const int32_t* src,
+                                const float* noise, int Sa, int Sb, int R, float invalid_sdf, float* rgba_a, float* rgba_b, void* stream)
+{
+    return guarded([&] {
+        if (!raw_a || !valid_a || !rgba_a) throw_error("vanerf_eval_func: null argument");
+        if (src && (!raw_b || !valid_b || !rgba_b || Sb <= 0)) throw_error("vanerf_eval_func: the merged order needs the second table");
+        if (!src && Sb != 0) throw_error("vanerf_eval_func: Sb = %d without an origin map", Sb);
+        if (R <= 0 || Sa <= 0) throw_error("vanerf_eval_func: R=%d Sa=%d", R, Sa);
+        const long long n = (long long)R * (Sa + Sb);
+        hipLaunchKernelGGL(eval_func_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, raw_a, valid_a, raw_b, valid_b, src, noise,
+                           Sa, Sb, n, invalid_sdf, rgba_a, rgba_b);
+        HIP_CHECK(hipGetLastError());
+    });
+}
+
 // Backward of the composite (training; the reference differentiates rgba2out with autograd: src/model.py:1464-1494, sdf_activation 879-882).  One wave per
 // ray, the forward quantities recomputed as composite_wave_kernel computes them, then with gw_i = dL/dw_i
 //   dL/dsigma_i = dist_i (gw_i T_{i+1} - sum_{k>i} gw_k w_k)        (T_{i+1} = T_i (1 - c_i); no division by (1 - c_i): exact zeros stay zeros, which is what

@@ -758,7 +758,7 @@ def render_pass_c(weights, frame, cam_tar, bounds, x0, y0, step, nx, ny, sample_
         draws = noise_draws if noise_draws is not None else (torch.randn(R * Sc, device=dev, generator=generator),
                                                              torch.randn(R * (Sc + Sf), device=dev, generator=generator) if fine else None)
         noise = tuple(None if t is None else (t.reshape(-1).to(dev, torch.float32) * noise_std).contiguous() for t in draws)
-    d.reuse_coarse = int(bool(reuse_coarse) and noise is None)
+    d.reuse_coarse = int(bool(reuse_coarse))  # (under noise: raw outputs once per point, eval_func per set of draws, as render_pass does)
     t_c, t_f = _t_lin(Sc, dev), _t_lin(Sf, dev) if fine else None
     d.t_lin_c, d.t_lin_f = _ptr(t_c), _ptr(t_f)
     d.jitter, d.u = _ptr(jitter, torch.float32), _ptr(u, torch.float32)
@@ -774,7 +774,7 @@ def render_pass_c(weights, frame, cam_tar, bounds, x0, y0, step, nx, ny, sample_
     o = VanerfPassOut()
     for k in ("index", "hit", "z", "color", "depth", "alpha", "color_fine", "depth_fine", "alpha_fine", "sdf", "z_fine"):
         setattr(o, k, _ptr(out.get(k)))
-    nbytes = int(lib.vanerf_render_pass_scratch(R, Sc, Sf, d.fine, d.reuse_coarse))
+    nbytes = int(lib.vanerf_render_pass_scratch(R, Sc, Sf, d.fine, 2 if d.reuse_coarse and noise is not None else d.reuse_coarse))
     scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     check(lib.vanerf_render_pass(weights.handle, byref(frame.c), byref(frame.accel.c), _ptr(frame.verts3, f32), frame.verts3.shape[0],
                                  _ptr(frame.faces, torch.int32), frame.faces.shape[0], byref(d), byref(o), _ptr(scratch), nbytes, _stream()))
