@@ -100,9 +100,17 @@ __global__ __launch_bounds__(BW_BLOCK, 1) void query_backward_kernel(const BwdPa
         S.vy = 4u * (unsigned)col + (unsigned)(4 * h) * S.row4;
         S.vy0 = h ? NO_COL : S.vy;
         auto X = [&](auto lc, auto tc) -> float {
+#ifdef VANERF_EXP_BWD_NOLOAD // timing experiment, wrong results: what the chain costs without its spill loads
+            return 1.0f;
+#endif
             return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(S.xs, S.vx, (unsigned)(x_row_base(decltype(lc)::value) + 2 * decltype(tc)::value) * S.row4, 0));
         };
-        auto AUX = [&](auto kc) -> float { return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(S.aux, S.vx, (unsigned)(2 * decltype(kc)::value) * S.row4, 0)); };
+        auto AUX = [&](auto kc) -> float {
+#ifdef VANERF_EXP_BWD_NOLOAD
+            return 0.5f;
+#endif
+            return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(S.aux, S.vx, (unsigned)(2 * decltype(kc)::value) * S.row4, 0));
+        };
         // IG spill: tensor at `off` floats per sample (x npad: wave-uniform), rows of `stride` floats; this lane's sample, channel ch
         auto IG1 = [&](int off, int stride, int ch, float v) {
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), S.ig, 4u * (S.col * (unsigned)stride + (unsigned)ch), (unsigned)off * S.row4, 0);
