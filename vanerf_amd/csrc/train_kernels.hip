@@ -7,6 +7,8 @@
 // atomics (a contended LDS atomic costs cycles, not a trip to the memory side), and flushes the slice once with global atomics.
 #include <algorithm>
 
+#include <cstdlib>
+
 #include "common.h"
 
 using namespace vanerf;
@@ -31,26 +33,57 @@ __global__ __launch_bounds__(SC_BLOCK) void scatter_rows_kernel(const int32_t* _
     constexpr int PER = SC_BLOCK / CS;
     const long long chunk = (n + gridDim.x - 1) / gridDim.x;
     const long long i0 = (long long)blockIdx.x * chunk, i1 = i0 + chunk < n ? i0 + chunk : n;
-    if (c0 + cl < C)
-        for (long long i = i0 + sub; i < i1; i += PER) {
-            const float v0 = g[i * g_ld + c0 + cl];
+    if (c0 + cl < C) {
+        // A thread owns one channel of a RUN of consecutive samples: consecutive depths of a ray keep their nearest vertex for many samples and move their
+        // bilinear taps by a fraction of a pixel, so a running (row, sum) per tap stays in registers and goes to the LDS table only when the row changes
+        // (the LDS float adds were the kernel's time: ~65 k of them per block and channel slice).  U samples per trip: all their loads (gradient row
+        // element, indices, weights) are issued before the first use -- one sample per trip was a chain of dependent global loads.
+        constexpr int U = 4, NS = TAPS + 1; // running sums: the taps, and the second source
+        const long long run = (chunk + PER - 1) / PER;
+        const long long a0 = i0 + (long long)sub * run, a1 = a0 + run < i1 ? a0 + run : i1;
+        int cur[NS];
+        float sum[NS];
 #pragma unroll
-            for (int k = 0; k < TAPS; ++k) {
-                const int r = idx[i + k * ld];
-                if ((unsigned)r >= (unsigned)R) continue; // an index outside the table contributes nothing (the forward gather would have faulted)
-                float v = v0;
-                if (w) v *= w[i + k * ld];
-                atomicAdd(&s_tab[r * CS + cl], v);
+        for (int k = 0; k < NS; ++k) { cur[k] = -1; sum[k] = 0.0f; }
+        auto push = [&](int k, int r, float v) {
+            if (r != cur[k]) {
+                if ((unsigned)cur[k] < (unsigned)R) atomicAdd(&s_tab[cur[k] * CS + cl], sum[k]); // (a row outside the table contributes nothing)
+                cur[k] = r; sum[k] = v;
+            } else {
+                sum[k] += v;
             }
-            if (TAPS == 1 && idx2) { // a second (index, weight, row) source into the same table: the nearest and the twin vertex row of a sample
-                const int r = idx2[i];
-                if ((unsigned)r < (unsigned)R) {
-                    float v = g2[i * g_ld + c0 + cl];
-                    if (w2) v *= w2[i];
-                    atomicAdd(&s_tab[r * CS + cl], v);
+        };
+        for (long long ib = a0; ib < a1; ib += U) {
+            float v0[U], wk[U][TAPS], v2[U], w2k[U];
+            int rk[U][TAPS], r2[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const long long i = ib + u;
+                const bool on = i < a1;
+                const long long ic = on ? i : a0; // (a valid address for the trips past the run's end; their rows are turned off)
+                v0[u] = g[ic * g_ld + c0 + cl];
+#pragma unroll
+                for (int k = 0; k < TAPS; ++k) {
+                    rk[u][k] = on ? idx[ic + k * ld] : -1;
+                    wk[u][k] = w ? w[ic + k * ld] : 1.0f;
+                }
+                if (TAPS == 1 && idx2) {
+                    r2[u] = on ? idx2[ic] : -1;
+                    v2[u] = g2[ic * g_ld + c0 + cl];
+                    w2k[u] = w2 ? w2[ic] : 1.0f;
                 }
             }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+#pragma unroll
+                for (int k = 0; k < TAPS; ++k) push(k, rk[u][k], w ? v0[u] * wk[u][k] : v0[u]);
+                if (TAPS == 1 && idx2) push(TAPS, r2[u], w2 ? v2[u] * w2k[u] : v2[u]); // the nearest and the twin vertex row of a sample
+            }
         }
+#pragma unroll
+        for (int k = 0; k < NS; ++k)
+            if ((unsigned)cur[k] < (unsigned)R) atomicAdd(&s_tab[cur[k] * CS + cl], sum[k]);
+    }
     __syncthreads();
     for (int k = threadIdx.x; k < R * CS; k += SC_BLOCK) {
         const float v = s_tab[k];
@@ -114,7 +147,8 @@ void scatter_rows(const int32_t* idx, const float* w, const float* g, int64_t g_
         // blocks = chunks x slices: 4 096 samples per chunk for a whole training patch (~5e5 samples), but never fewer than ~512 blocks' worth of
         // work in flight -- the fused backward calls this once per block of 65 536 samples, where 16 chunks x 4 slices left three quarters of the chip idle
         int chunks = (int)((n + 4095) / 4096);
-        const int fill = (int)std::min<long long>((n + 511) / 512, 512 / slices > 0 ? 512 / slices : 1);
+        static const int fill_blocks = [] { const char* e = getenv("VANERF_SCATTER_FILL"); return e ? atoi(e) : 256; }(); // (256 / 512 / 1024 blocks' worth measured: 12.2 / 12.6 / 12.6 ms of the step's fused stage)
+        const int fill = (int)std::min<long long>((n + 511) / 512, fill_blocks / slices > 0 ? fill_blocks / slices : 1);
         if (chunks < fill) chunks = fill;
         if (chunks > 1024 / slices) chunks = 1024 / slices > 0 ? 1024 / slices : 1;
         if (chunks < 1) chunks = 1;
