@@ -325,6 +325,9 @@ int vanerf_render_pass(const VanerfWeights* w, const VanerfFrame* frame, const V
  * slices of the table instead of contended global atomics.                                                                               */
 /* g_ld: floats between consecutive rows of g (0 = C: packed rows).                                                                        */
 int vanerf_scatter_add_rows(const int32_t* idx, const float* w, const float* g, int64_t g_ld, int64_t n, int C, float* table, int R, void* stream);
+/* the four bilinear taps of feat_sample (src/utils.py:136-151; border padding, align_corners) at xy[n][2] in [-1, 1] on an H x W map: idx4 / w4 = [4][n], the
+ * row indices of the channel-last map and the weights vanerf_scatter_add_taps takes                                                              */
+int vanerf_bilinear_taps(const float* xy, int64_t n, int H, int W, int32_t* idx4, float* w4, void* stream);
 /* two sources into one table in one launch (the nearest and the twin vertex row of a sample): table[idx[i]] += w[i] g[i], table[idx2[i]] += w2[i] g2[i] */
 int vanerf_scatter_add_rows2(const int32_t* idx, const float* w, const float* g, const int32_t* idx2, const float* w2, const float* g2, int64_t g_ld,
                              int64_t n, int C, float* table, int R, void* stream);

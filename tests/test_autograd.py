@@ -477,3 +477,18 @@ def test_composite_backward_against_autograd(S, Sn):
             close(d_n, grads[2], "d_rgba_n")
         assert abs(d_beta.double().sum().item() - grads[1].item()) <= 2e-3 * abs(grads[1].item()) + 1e-3, (d_beta.double().sum().item(), grads[1].item())
         assert torch.isfinite(d_a).all() and torch.isfinite(d_beta).all()
+
+
+def test_bilinear_taps_kernel_against_the_torch_formula():
+    """vanerf_bilinear_taps (row indices and weights of feat_sample's four taps, one launch) against the element-wise torch version it replaced:
+    indices equal, weights within rounding, coordinates outside [-1, 1] clamped to the border, a one-pixel-wide map."""
+    from vanerf_amd import hip_backward as HB
+    g = torch.Generator(device="cuda").manual_seed(0)
+    for H, W in ((64, 64), (128, 96), (1, 7), (5, 1)):
+        xy = torch.rand(10007, 2, device="cuda", generator=g) * 2.6 - 1.3
+        xy[:8] = torch.tensor([[-1.0, -1.0], [1.0, 1.0], [0.0, 0.0], [1.0, -1.0], [-1.3, 0.2], [0.999999, 0.5], [-0.999999, -0.5], [2.0, 2.0]], device="cuda")
+        i_k, w_k = HB._taps(xy, H, W)
+        i_t, w_t = HB._taps(xy, H, W, use_torch=True)
+        assert torch.equal(i_k, i_t), (H, W)
+        assert (w_k - w_t).abs().max().item() <= 1e-6, (H, W)
+        assert (w_k.sum(0) - 1.0).abs().max().item() <= 1e-6

@@ -113,6 +113,7 @@ _SIGS = {
     "vanerf_render_pass": (c_int, [c_void_p, POINTER(VanerfFrame), POINTER(VanerfMeshAccel), _FP, c_int, _FP, c_int, POINTER(VanerfPassDesc),
                                    POINTER(VanerfPassOut), _FP, c_int64, c_void_p]),
     "vanerf_scatter_add_rows": (c_int, [_FP, _FP, _FP, c_int64, c_int64, c_int, _FP, c_int, c_void_p]),
+    "vanerf_bilinear_taps": (c_int, [_FP, c_int64, c_int, c_int, _FP, _FP, c_void_p]),
     "vanerf_scatter_add_rows2": (c_int, [_FP, _FP, _FP, _FP, _FP, _FP, c_int64, c_int64, c_int, _FP, c_int, c_void_p]),
     "vanerf_scatter_add_taps": (c_int, [_FP, _FP, c_int64, _FP, c_int64, c_int64, c_int, _FP, c_int, c_void_p]),
     "vanerf_ig_tensor": (c_int, [c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int)]),

@@ -92,7 +92,33 @@ __global__ __launch_bounds__(SC_BLOCK) void scatter_rows_kernel(const int32_t* _
     }
 }
 
+// the four bilinear taps of feat_sample (src/utils.py:136-151: border padding, align_corners) at xy in [-1, 1]: row indices of the channel-last
+// map and weights, [4][n] each -- the arithmetic of the forward kernels' bilin_setup
+__global__ __launch_bounds__(256) void bilinear_taps_kernel(const float* __restrict__ xy, long long n, int H, int W, int32_t* __restrict__ idx4,
+                                                            float* __restrict__ w4)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float wm1 = (float)(W - 1), hm1 = (float)(H - 1);
+    float x = (xy[2 * i] + 1.0f) * (0.5f * wm1), y = (xy[2 * i + 1] + 1.0f) * (0.5f * hm1);
+    x = fminf(fmaxf(x, 0.0f), wm1); y = fminf(fmaxf(y, 0.0f), hm1);
+    const float xf = floorf(x), yf = floorf(y), wx = x - xf, wy = y - yf;
+    const int x0 = (int)xf, y0 = (int)yf, x1 = x0 + 1 < W ? x0 + 1 : W - 1, y1 = y0 + 1 < H ? y0 + 1 : H - 1;
+    idx4[i] = y0 * W + x0; idx4[n + i] = y0 * W + x1; idx4[2 * n + i] = y1 * W + x0; idx4[3 * n + i] = y1 * W + x1;
+    w4[i] = (1.0f - wx) * (1.0f - wy); w4[n + i] = wx * (1.0f - wy); w4[2 * n + i] = (1.0f - wx) * wy; w4[3 * n + i] = wx * wy;
+}
+
 } // namespace
+
+extern "C" int vanerf_bilinear_taps(const float* xy, int64_t n, int H, int W, int32_t* idx4, float* w4, void* stream)
+{
+    return guarded([&] {
+        if (n == 0) return;
+        if (!xy || !idx4 || !w4 || n < 0 || H <= 0 || W <= 0) throw_error("vanerf_bilinear_taps: n=%lld H=%d W=%d or a null argument", (long long)n, H, W);
+        hipLaunchKernelGGL(bilinear_taps_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, xy, (long long)n, H, W, idx4, w4);
+        HIP_CHECK(hipGetLastError());
+    });
+}
 
 // table[R][C] += scatter of w[i] * g[i][C] at rows idx[i] (w may be NULL = 1).  All device pointers; `table` is accumulated into (zero it first
 // for a plain gradient).  Rows outside [0, R) are ignored.

@@ -197,9 +197,17 @@ def workspace(block, device):
     return _WS[key]
 
 
-def _taps(xy, H, W):
+def _taps(xy, H, W, use_torch=False):
     """The four bilinear taps of feat_sample (src/utils.py:136-151; border padding, align_corners) at (n, 2) coordinates in [-1, 1]:
-    int32 row indices of the channel-last map [4][n] and their weights [4][n] -- the kernel's bilin_setup, same arithmetic."""
+    int32 row indices of the channel-last map [4][n] and their weights [4][n] -- the kernel's bilin_setup, same arithmetic
+    (vanerf_bilinear_taps: one launch; use_torch: the ~15 element-wise launches it replaced, kept as the checker)."""
+    if not use_torch:
+        n = xy.shape[0]
+        xy = xy.to(torch.float32).contiguous()
+        idx = torch.empty(4, n, dtype=torch.int32, device=xy.device)
+        w = torch.empty(4, n, dtype=torch.float32, device=xy.device)
+        check(lib.vanerf_bilinear_taps(_ptr(xy), n, int(H), int(W), _ptr(idx), _ptr(w), R._stream()))
+        return idx, w
     x = ((xy[:, 0] + 1.0) * (0.5 * (W - 1))).clamp(0.0, W - 1.0)
     y = ((xy[:, 1] + 1.0) * (0.5 * (H - 1))).clamp(0.0, H - 1.0)
     x0, y0 = x.floor(), y.floor()
