@@ -354,10 +354,10 @@ int vanerf_query_forward_spill(const VanerfWeights* w, const VanerfFrame* frame,
 int vanerf_query_backward(const VanerfWeights* w, const float* d, const float* d2, const float* noise, const float* noise2, const float* raw,
                           const uint8_t* valid, int64_t n, int64_t npad, const float* xs, const float* aux, float* ys, float* ig, void* stream);
 int vanerf_spill_rows(int* x_rows, int* y_rows, int* aux_rows, int* ig_rows);
-/* The weight gradients of a block: dw[layer l at layout_slices x (sum of n_out x n_slots over the layers before l)][slice][n_out][n_slots] += ys_l xs_l^T
- * over the slice's samples, every layer in one launch (slices: the block's samples are cut into this many parts that accumulate separately -- the caller
- * sums them once per step; npad must be a multiple of 32 x slices; slices <= layout_slices, the slicing the accumulator was laid out for).  One wave per
- * (tile group, slice): no atomics, reproducible.                                                                                                  */
+/* The weight gradients of a block: dw[slice][layer l at (sum of n_out x n_slots over the layers before l)][n_out][n_slots] += ys_l xs_l^T over the slice's
+ * samples, every layer in one launch (slices: the block's samples are cut into this many parts that accumulate separately -- the caller sums dw over its
+ * first dimension once per step; npad must be a multiple of 32 x slices; slices <= layout_slices, the number of parts dw has room for;
+ * vanerf_weight_products_size: floats per part).  One wave per (tile group, slice): no atomics, reproducible.                                       */
 int vanerf_weight_products(const float* xs, const float* ys, int64_t npad, int slices, int layout_slices, float* dw, void* stream);
 int vanerf_weight_products_size(int64_t* floats_per_slice);
 /* Tensor `which` of the ig spill: 0..2 pixel feature / nearest / twin vertex row of GeoVisFusion's scale 0 (64 channels), 3..5 the same of scale 1

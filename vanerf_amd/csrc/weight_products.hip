@@ -26,8 +26,8 @@ struct WpTask {
     int y_row, x_row;   // first row of the group in Ys / Xs
     int n_out, n_slot;  // rows of the layer left from there (the group uses min(., 32 MG) / min(., 32 NG))
     int ld;             // slots of the layer (row length of its accumulator)
-    unsigned dw_off;    // offset of the layer's accumulator [slices][n_out_layer][ld] in floats ...
-    unsigned dw_layer;  // ... and its size per slice
+    unsigned dw_off;    // offset of the layer's accumulator [n_out_layer][ld] inside a slice of the accumulator, in floats ...
+    unsigned dw_layer;  // ... and the floats per slice (all layers)
     int out0, slot0;    // the group's first output row / slot inside the layer
 };
 
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256, 1) void weight_products_kernel(const WpTask* _
         products();
     }
     // accumulate: register r of lane l holds row (r & 3) + 8 (r >> 2) + 4 (l >> 5), column l & 31 of the tile
-    float* out = dw + T.dw_off + (size_t)slice * T.dw_layer;
+    float* out = dw + (size_t)slice * T.dw_layer + T.dw_off; // dw[slice][all layers]: T.dw_layer = floats per slice, T.dw_off = the layer's offset in it
 #pragma unroll
     for (int m = 0; m < MG; ++m) {
         if (m >= mt_n) break;
@@ -160,15 +160,17 @@ const TaskTable& task_table()
             off += (unsigned)(kNOUT[l] * 2 * kT[l]);
         }
         tt.total = off;
+        const unsigned total = off;
         for (int l = 0; l < NUM_LAYERS; ++l)
             for (int o = 0; o < kNOUT[l]; o += 32 * MG)
                 for (int c = 0; c < 2 * kT[l]; c += 32 * NG) {
                     WpTask t{};
                     t.y_row = y_row_base(l) + o; t.x_row = x_row_base(l) + c;
                     t.n_out = kNOUT[l] - o; t.n_slot = 2 * kT[l] - c; t.ld = 2 * kT[l];
-                    t.dw_off = 0; t.dw_layer = (unsigned)(kNOUT[l] * 2 * kT[l]); t.out0 = o; t.slot0 = c;
+                    t.dw_off = 0; t.dw_layer = 0; t.out0 = o; t.slot0 = c;
                     t.x_row = x_row_base(l) + c;
-                    t.dw_off = lays[l].off; // x slices: filled in per launch (the layer's accumulator starts at slices x this)
+                    t.dw_off = lays[l].off;
+                    t.dw_layer = total;
                     tt.host.push_back(t);
                 }
         // heavy groups first: the four waves of a block then carry similar work, and the launch ends on the light ones
@@ -189,7 +191,6 @@ const DevTable& device_table(int device, int slices)
     for (auto& e : cache)
         if (e.first == std::make_pair(device, slices)) return e.second;
     std::vector<WpTask> h = task_table().host;
-    for (WpTask& t : h) t.dw_off *= (unsigned)slices;
     DevTable d;
     d.n = (int)h.size();
     HIP_CHECK(hipMalloc(&d.dev, h.size() * sizeof(WpTask)));
@@ -200,7 +201,7 @@ const DevTable& device_table(int device, int slices)
 
 } // namespace
 
-// dw: layout_slices x (sum over the layers of n_out x n_slots) floats, layer l at layout_slices x (its offset), [layout_slices][n_out][n_slots] -- accumulated into.
+// dw: [layout_slices][sum over the layers of n_out x n_slots] floats (slice-major: one sum over the first dimension closes a step), accumulated into.
 // slices <= layout_slices: a block too short to be cut `layout_slices` times accumulates into the first `slices` parts of the same accumulator.
 extern "C" int vanerf_weight_products(const float* xs, const float* ys, int64_t npad, int slices, int layout_slices, float* dw, void* stream)
 {

@@ -84,9 +84,9 @@ class Workspace:
         self.valid = torch.empty(npad, dtype=torch.uint8, device=device)
         # weight-gradient accumulators: per layer (SLICES, n_out, n_slots), summed over the slices once per step (parameter_gradients)
         self.slices = SLICES if npad % SLICES == 0 and npad // SLICES >= 32 else 1
-        self.dw = torch.zeros(self.slices * L["flat"], dtype=f32, device=device)
-        self.dw_l = [self.dw[self.slices * lay["flat"]:self.slices * (lay["flat"] + lay["n_out"] * lay["n_slots"])].view(self.slices, lay["n_out"], lay["n_slots"])
-                     for lay in L["layers"]]
+        self.dw = torch.zeros(self.slices * L["flat"], dtype=f32, device=device)  # [slice][all layers]: one sum over the slices closes a step
+        by_slice = self.dw.view(self.slices, L["flat"])
+        self.dw_l = [by_slice[:, lay["flat"]:lay["flat"] + lay["n_out"] * lay["n_slots"]].view(self.slices, lay["n_out"], lay["n_slots"]) for lay in L["layers"]]
 
     def bytes(self):
         return sum(t.numel() * t.element_size() for t in (self.xs, self.aux, self.ys, self.ig, self.raw, self.valid, self.dw))
@@ -132,41 +132,56 @@ def _weight_products_on(ws, xs, ys, npad, use_torch=False):
         torch.baddbmm(a, g.view(lay["n_out"], S, per).transpose(0, 1), x.view(lay["n_slots"], S, per).permute(1, 2, 0), out=a)
 
 
-_SLOTS_ON = {}
+_MAPS = {}
 
 
-def _slot_tables(device):
-    """Per layer, on the device, once: (slots with a channel, their channels, the bias slot or None)."""
+def _channel_maps(device, P):
+    """Once per device: where every slot of the flat accumulator goes in a flat [all layers][n_out][kin] channel-space vector (slots that carry
+    no channel, and the bias slots, are left out), the bias slots' positions, and the layers' offsets / shapes there."""
     key = str(device)
-    if key not in _SLOTS_ON:
-        tabs = []
-        for lay in layout()["layers"]:
-            sl = lay["slots"]
+    if key not in _MAPS:
+        L = layout()
+        src, dst, bias_src, shapes, at = [], [], [], [], 0
+        for lay, spec in zip(L["layers"], LAYER_PARAMS):
+            kind = spec[0]
+            ref = P[spec[1]] if kind == "conv" else P[spec[1] + (".weight_v" if kind == "wn" else ".weight")]
+            kin, n_out, n_slots, sl = ref.shape[1], lay["n_out"], lay["n_slots"], lay["slots"]
             cols = (sl >= 0).nonzero().view(-1)
-            bias = (sl == -2).nonzero().view(-1)
-            tabs.append((cols.to(device), sl[cols].to(device), int(bias[0]) if bias.numel() else None))
-        _SLOTS_ON[key] = tabs
-    return _SLOTS_ON[key]
+            o = torch.arange(n_out)[:, None]
+            src.append((lay["flat"] + o * n_slots + cols[None, :]).reshape(-1))
+            dst.append((at + o * kin + sl[cols][None, :]).reshape(-1))
+            b = (sl == -2).nonzero().view(-1)
+            bias_src.append(lay["flat"] + torch.arange(n_out) * n_slots + int(b[0]) if b.numel() else None)
+            shapes.append((at, n_out, kin))
+            at += n_out * kin
+        _MAPS[key] = {"src": torch.cat(src).to(device), "dst": torch.cat(dst).to(device), "bias": [None if b is None else b.to(device) for b in bias_src],
+                      "shapes": shapes, "total": at}
+    return _MAPS[key]
 
 
 def parameter_gradients(ws, P):
-    """The flat accumulator -> gradients of the reference's parameters (dict key -> tensor).  P: name -> leaf tensor."""
+    """The flat accumulator(s) -> gradients of the reference's parameters (dict key -> tensor).  P: name -> leaf tensor.
+    ws: a Workspace or a list of them (summed in list order).  One sum over the slices and one index_add for all twenty layers (slot -> input
+    channel; duplicated operands add up), then views; weight-norm through autograd of the fold itself."""
     L = layout()
+    wss = ws if isinstance(ws, (list, tuple)) else [ws]
+    flat = wss[0].dw.view(wss[0].slices, L["flat"]).sum(0)
+    for other in wss[1:]:
+        flat = flat + other.dw.view(other.slices, L["flat"]).sum(0)
+    M = _channel_maps(flat.device, P)
+    chan = torch.zeros(M["total"], dtype=torch.float32, device=flat.device).index_add_(0, M["dst"], flat[M["src"]])
     out = {}
-    tabs = _slot_tables(ws.dw.device)
     for li, (lay, spec) in enumerate(zip(L["layers"], LAYER_PARAMS)):
-        dwp = ws.dw_l[li].sum(0)
-        cols, chans, bias_slot = tabs[li]
+        at, n_out, kin = M["shapes"][li]
+        dw = chan[at:at + n_out * kin].view(n_out, kin)
         kind = spec[0]
-        ref = P[spec[1]] if kind == "conv" else P[spec[1] + (".weight_v" if kind == "wn" else ".weight")]
-        kin = ref.shape[1]
-        dw = torch.zeros(lay["n_out"], kin, dtype=torch.float32, device=dwp.device).index_add_(1, chans, dwp[:, cols])
         if kind == "conv":
+            ref = P[spec[1]]
             g = torch.zeros_like(ref)
-            g[:lay["n_out"], :, 0] = dw  # (fconv.2 has 40 output channels, of which one view uses 3: src/model.py:1613, 1635)
+            g[:n_out, :, 0] = dw  # (fconv.2 has 40 output channels, of which one view uses 3: src/model.py:1613, 1635)
             out[spec[1]] = g
             continue
-        out[spec[1] + ".bias"] = dwp[:, bias_slot].clone()
+        out[spec[1] + ".bias"] = flat[M["bias"][li]]
         if kind == "lin":
             out[spec[1] + ".weight"] = dw
         else:  # weight-norm fold W = v g / ||v||_row (src/utils.py:674-675), differentiated by autograd itself
