@@ -112,16 +112,28 @@ __global__ __launch_bounds__(256, 1) void weight_products_kernel(const WpTask* _
             }
         }
     };
-    fetch(g0, 0);
-    if (32 < per) fetch(g1, 4 * 32);
+#ifdef VANERF_EXP_WP_NOLOAD // timing experiments, wrong results: 1 = no global loads and no staging (products on whatever the LDS holds), 2 = no products
+#define VANERF_WP_FETCH(g, s) ((void)0)
+#define VANERF_WP_STAGE(g) ((void)0)
+#else
+#define VANERF_WP_FETCH(g, s) fetch(g, s)
+#define VANERF_WP_STAGE(g) stage(g)
+#endif
+#ifdef VANERF_EXP_WP_NOMFMA
+#define VANERF_WP_PRODUCTS() ((void)0)
+#else
+#define VANERF_WP_PRODUCTS() products()
+#endif
+    VANERF_WP_FETCH(g0, 0);
+    if (32 < per) VANERF_WP_FETCH(g1, 4 * 32);
     for (long long s = 0; s < per; s += 64) {
-        stage(g0);                                 // (LDS operations of a wave execute in order: the previous batch's reads are ahead of these writes)
-        if (s + 64 < per) fetch(g0, (unsigned)(4 * (s + 64)));
-        products();
+        VANERF_WP_STAGE(g0);                       // (LDS operations of a wave execute in order: the previous batch's reads are ahead of these writes)
+        if (s + 64 < per) VANERF_WP_FETCH(g0, (unsigned)(4 * (s + 64)));
+        VANERF_WP_PRODUCTS();
         if (s + 32 >= per) break;
-        stage(g1);
-        if (s + 96 < per) fetch(g1, (unsigned)(4 * (s + 96)));
-        products();
+        VANERF_WP_STAGE(g1);
+        if (s + 96 < per) VANERF_WP_FETCH(g1, (unsigned)(4 * (s + 96)));
+        VANERF_WP_PRODUCTS();
     }
     // accumulate: register r of lane l holds row (r & 3) + 8 (r >> 2) + 4 (l >> 5), column l & 31 of the tile
     float* out = dw + (size_t)slice * T.dw_layer + T.dw_off; // dw[slice][all layers]: T.dw_layer = floats per slice, T.dw_off = the layer's offset in it
