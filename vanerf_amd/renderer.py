@@ -662,12 +662,13 @@ def render_pass(weights, frame, cam_tar, bounds, x0, y0, step, nx, ny, sample_pe
         return (draws * noise_std).contiguous()
 
     def eval_func(raw, valid, noise):
-        """src/model.py:1140-1160 on the kernel's raw outputs [sdf_pred, rad, r, g, b]: the same fp32 operations in the same order as the
-        kernel's own epilogue (csrc/query_kernel.hip), so the same bits."""
-        mask = valid.to(torch.float32)
-        alpha = mask * torch.clamp_min(raw[:, 1] + noise, 0.0)
-        sdf = mask * raw[:, 0] + (1.0 - mask) * float(frame.c.invalid_sdf)
-        return torch.stack([alpha, sdf, raw[:, 2], raw[:, 3], raw[:, 4]], 1).contiguous()
+        """src/model.py:1140-1160 on the kernel's raw outputs [sdf_pred, rad, r, g, b] (vanerf_eval_func: the arithmetic of the kernel's own
+        epilogue, csrc/query_kernel.hip, so the same bits; one launch instead of eight element-wise ones)."""
+        n = raw.shape[0]
+        out = torch.empty(n, 5, dtype=torch.float32, device=raw.device)
+        check(lib.vanerf_eval_func(_ptr(raw, torch.float32), _ptr(valid, torch.uint8), None, None, None, _ptr(noise, torch.float32), 1, 0, n,
+                                   float(frame.c.invalid_sdf), _ptr(out), None, _stream()))
+        return out
 
     def evaluate(z, draws=None, raw=False):
         pts = sample_points(rays["rays_d"], rays["cam_pos"], z)
