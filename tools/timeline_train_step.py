@@ -57,5 +57,5 @@ for (name, a), (_, b) in zip(marks, marks[1:]):
         k = e.name[:70]
         c = by.setdefault(k, [0, 0.0]); c[0] += 1; c[1] += e.time_range.end - e.time_range.start
     print(f"\n{name}: {len(seg)} kernels, busy {1e-3 * dur:.2f} ms, span {1e-3 * span:.2f} ms")
-    for k, (c, t) in sorted(by.items(), key=lambda kv: -kv[1][1])[:(24 if "stage 2" in name else 9)]:
+    for k, (c, t) in sorted(by.items(), key=lambda kv: -kv[1][1])[:(24 if "stage 2" in name else 40 if "render pass" in name else 9)]:
         print(f"    {1e-3 * t:6.2f} ms  {c:4d} x  {k}")
