@@ -1144,7 +1144,7 @@ extern "C" int vanerf_query_forward_spill(const VanerfWeights* w, const VanerfFr
         int dev = 0, cus = 256;
         HIP_CHECK(hipGetDevice(&dev));
         HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-        if (blocks > cus) blocks = cus; // one 4-wave block per CU (the spill build takes the whole register file: at 256 registers it goes to scratch)
+        if (blocks > (long long)cus * VANERF_WAVES_PER_SIMD_SPILL) blocks = (long long)cus * VANERF_WAVES_PER_SIMD_SPILL; // one 4-wave block per CU (the spill build takes the whole register file: at 256 registers it goes to scratch)
         P.queue = static_cast<unsigned*>(queue_word);
         HIP_CHECK(hipMemsetAsync(P.queue, 0, 8, (hipStream_t)stream));
         hipLaunchKernelGGL((query_kernel<0, true>), dim3((unsigned)blocks), dim3(64 * WPB<0>), 0, (hipStream_t)stream, P);
