@@ -56,6 +56,22 @@ def _check_no_scratch(src, remarks):
                            "work loop; make the stride opaque per iteration (query_backward.hip) (VANERF_ALLOW_SCRATCH=1 builds anyway)")
 
 
+def _check_wide_stores(src, asm_path):
+    """A 12/16-byte buffer store whose offset sits in an SGPR reads its data registers late; one build of query_backward_kernel had a
+    v_pk_mov_b32 into them directly behind such a store (lanes 12-15 / 28-31 of one channel stored the next value, differently from run to
+    run; the compiler inserted no wait state).  No kernel of this library may contain the pattern: wide buffer stores keep their whole
+    offset in the VGPR (literal 0 as the scalar offset)."""
+    bad = []
+    try:
+        text = open(asm_path).read()
+    except OSError:
+        return
+    for m in re.finditer(r"buffer_store_dwordx[34]\s+v\[\d+:\d+\],\s*v\d+,\s*s\[\d+:\d+\],\s*(s\d+|m0|ttmp\d+)\b[^\n]*", text):
+        bad.append(m.group(0).strip())
+    if bad and os.environ.get("VANERF_ALLOW_SCRATCH") != "1":
+        raise RuntimeError(f"{src}: {len(bad)} wide buffer store(s) with an SGPR offset (store-data hazard), e.g. `{bad[0]}`")
+
+
 def build(force=False, verbose=False, extra=(), out=None):
     """out: build an experiment variant into another file (tools/build_variants.py); the product library is LIB."""
     extra = tuple(extra) + tuple(os.environ.get("VANERF_HIPCC_FLAGS", "").split())
@@ -68,7 +84,7 @@ def build(force=False, verbose=False, extra=(), out=None):
         obj = os.path.join(HERE, "lib", src + ".o") if out is None else out + "." + src + ".o"
         cmd = [hipcc, *FLAGS, *FILE_FLAGS.get(src, []), *extra, "-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
         if src.endswith(".hip"):
-            cmd[1:1] = ["-Rpass-analysis=kernel-resource-usage", "-fno-caret-diagnostics"]  # remarks without source snippets
+            cmd[1:1] = ["-Rpass-analysis=kernel-resource-usage", "-fno-caret-diagnostics", "-save-temps=obj"]  # remarks without source snippets; the device assembly for _check_wide_stores
         if verbose:
             print(" ".join(cmd), flush=True)
         res = subprocess.run(cmd, capture_output=True, text=True)
@@ -79,6 +95,12 @@ def build(force=False, verbose=False, extra=(), out=None):
         if res.returncode != 0:
             raise subprocess.CalledProcessError(res.returncode, cmd)
         _check_no_scratch(src, remarks)
+        if src.endswith(".hip"):
+            stem = os.path.join(os.path.dirname(obj), os.path.splitext(src)[0])
+            _check_wide_stores(src, stem + "-hip-amdgcn-amd-amdhsa-gfx950.s")
+            for f in os.listdir(os.path.dirname(obj)):  # the other intermediates of -save-temps
+                if f.startswith(os.path.splitext(src)[0] + "-h") or f.startswith(src + "-hip-"):
+                    os.remove(os.path.join(os.path.dirname(obj), f))
         objs.append(obj)
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out or LIB, *objs]
     if verbose:
