@@ -1113,6 +1113,44 @@ def test_weights_update_on_the_device_equals_a_fresh_pack(R, sd_full, precision)
         w.update(other)  # host tensors: the device packer refuses, it never copies
 
 
+def test_eval_func_kernel_against_the_formula(R):
+    """vanerf_eval_func: [sdf_pred, rad, r, g, b] -> [alpha, sdf, r, g, b] = [mask relu(rad + noise), mask sdf_pred + (1 - mask) invalid_sdf, colour]
+    (src/model.py:1140-1160), entry by entry and through a merged order's origin map (each table entry written once, in place allowed), bit for bit
+    against the same fp32 operations in torch."""
+    import ctypes
+    from vanerf_amd._ffi import lib, check
+    g = torch.Generator(device="cuda").manual_seed(3)
+    rays, Sa, Sb, inv = 37, 12, 5, 0.0125
+    P = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
+    st = R._stream()
+
+    def formula(raw, valid, noise):
+        mask = valid.float()
+        return torch.stack([mask * torch.clamp_min(raw[..., 1] + noise, 0.0), mask * raw[..., 0] + (1.0 - mask) * inv, raw[..., 2], raw[..., 3], raw[..., 4]], -1)
+
+    raw_a = torch.randn(rays, Sa, 5, device="cuda", generator=g)
+    val_a = (torch.rand(rays, Sa, device="cuda", generator=g) > 0.3).to(torch.uint8)
+    noise = torch.randn(rays, Sa, device="cuda", generator=g) * 0.5
+    out = torch.empty_like(raw_a)
+    check(lib.vanerf_eval_func(P(raw_a), P(val_a), None, None, None, P(noise), Sa, 0, rays, inv, P(out), None, st))
+    assert torch.equal(out, formula(raw_a, val_a, noise))
+    check(lib.vanerf_eval_func(P(raw_a), P(val_a), None, None, None, None, Sa, 0, rays, inv, P(out), None, st))  # no noise
+    assert torch.equal(out, formula(raw_a, val_a, torch.zeros_like(noise)))
+    # merged order: position p of a ray names its entry, noise per position
+    raw_b = torch.randn(rays, Sb, 5, device="cuda", generator=g)
+    val_b = (torch.rand(rays, Sb, device="cuda", generator=g) > 0.3).to(torch.uint8)
+    perm = torch.argsort(torch.rand(rays, Sa + Sb, device="cuda", generator=g), dim=1)
+    src = torch.where(perm < Sa, perm, -(perm - Sa) - 1).to(torch.int32).contiguous()
+    noise_m = torch.randn(rays, Sa + Sb, device="cuda", generator=g) * 0.5
+    pos = torch.empty_like(perm).scatter_(1, perm, torch.arange(Sa + Sb, device="cuda").expand(rays, -1))  # entry -> position
+    want_a = formula(raw_a, val_a, noise_m.gather(1, pos[:, :Sa]))
+    want_b = formula(raw_b, val_b, noise_m.gather(1, pos[:, Sa:]))
+    out_a, in_place_b = torch.empty_like(raw_a), raw_b.clone()
+    check(lib.vanerf_eval_func(P(raw_a), P(val_a), P(in_place_b), P(val_b), P(src), P(noise_m), Sa, Sb, rays, inv, P(out_a), P(in_place_b), st))
+    assert torch.equal(out_a, want_a) and torch.equal(in_place_b, want_b)
+    assert lib.vanerf_eval_func(P(raw_a), P(val_a), None, None, P(src), P(noise_m), Sa, Sb, rays, inv, P(out_a), None, st) < 0  # merged order without table b
+
+
 def test_scatter_add_rows(R):
     """vanerf_scatter_add_rows (backward of the row gathers of a training step) against torch.index_add_: tables of 1 024 x 64, 16 384 x 8 and
     1 558 x 29 rows x channels, heavy index duplication, optional per-sample weights, out-of-range rows ignored, accumulation into a non-zero table."""

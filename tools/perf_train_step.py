@@ -29,7 +29,7 @@ net.load_state_dict(synth.make_full_weights(0), strict=False)
 frame = synth.to_device(synth.make_frame(seed=3, tar_h=256, tar_w=256), "cuda")
 dr = {"img": frame["img_in"], "cam": frame["cam_in"], "cam_tar": frame["cam_tar"], "tar": torch.rand(1, 3, 256, 256, device="cuda"),
       "msk": torch.ones(1, 1, 256, 256, device="cuda")}
-opt = torch.optim.Adam(net.parameters(), lr=1e-5)
+opt = torch.optim.Adam(net.parameters(), lr=1e-5, fused=("--fused_adam" in sys.argv) or None)  # (--fused_adam: one launch per dtype group; default: PyTorch's foreach path)
 PIPELINED = "--pipelined" in sys.argv  # no read of the loss per step: the host runs ahead of the GPU across the step boundary (a training loop
 #                                       that logs every few steps); the time reported is then the average of 10 back-to-back steps
 def step():
