@@ -26,6 +26,10 @@ if "--graph_encoders" in sys.argv:  # the two image encoders as HIP graphs (forw
 torch.backends.cudnn.benchmark = "--cudnn_benchmark" in sys.argv
 net = VANeRF(cfg).cuda().train()
 net.load_state_dict(synth.make_full_weights(0), strict=False)
+if "--channels_last" in sys.argv:  # experiment: the two image encoders' convolutions in NHWC
+    for enc in (net.geo_encoder, net.tex_encoder):
+        if enc is not None:
+            enc.to(memory_format=torch.channels_last)
 frame = synth.to_device(synth.make_frame(seed=3, tar_h=256, tar_w=256), "cuda")
 dr = {"img": frame["img_in"], "cam": frame["cam_in"], "cam_tar": frame["cam_tar"], "tar": torch.rand(1, 3, 256, 256, device="cuda"),
       "msk": torch.ones(1, 1, 256, 256, device="cuda")}
